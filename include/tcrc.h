@@ -1,0 +1,104 @@
+/*
+ * tcrc - batched masked-CRC32C engine for AMD Instinct MI355X (gfx950).
+ *
+ * C ABI of libtcrc.so.  Plain pointers and sizes only.  The library replaces the
+ * checksum arithmetic on TerarkDB's per-record path; each entry point names the
+ * reference interface it stands in for (paths relative to the reference tree).
+ *
+ * Conventions
+ *   - "d_" arguments are device pointers valid on the context's GPU; "h_" are host.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Device
+ *     entry points only enqueue work: results are ready once the stream is synced.
+ *   - return value: TCRC_OK or a negative TCRC_ERR_* code; tcrc_last_error() gives
+ *     text.  A checksum MISMATCH is data, never an error code.
+ *   - CRC values follow the reference: Extend(init, data, n) takes and returns
+ *     finalised CRCs (util/crc32c.h:23-29); masked values are Mask() of those
+ *     (util/crc32c.h:38-41).
+ */
+#ifndef TCRC_H_
+#define TCRC_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TCRC_OK 0
+#define TCRC_ERR_INVALID (-1)   /* bad argument */
+#define TCRC_ERR_NO_DEVICE (-2) /* no usable GPU / HIP runtime failure at init */
+#define TCRC_ERR_HIP (-3)       /* a HIP call failed */
+#define TCRC_ERR_TOO_LARGE (-4) /* size beyond what the entry point supports */
+
+typedef struct tcrc_ctx tcrc_ctx;
+
+/* One buffer of a batch: bytes [offset, offset+len) of the batch's base pointer,
+ * checksummed as Extend(init, ...).  init = 0 gives Value(). */
+typedef struct tcrc_desc {
+  uint64_t offset;
+  uint32_t len;
+  uint32_t init;
+} tcrc_desc;
+
+/* flags */
+#define TCRC_F_MASK 0x1u          /* outputs are Mask(crc) instead of crc */
+#define TCRC_F_EXPECT_AFTER 0x2u  /* verify: stored value is the LE32 right after the buffer (SST trailer) */
+#define TCRC_F_EXPECT_BEFORE 0x4u /* verify: stored value is the LE32 six bytes before the buffer (WAL header) */
+
+/* verify result block (device memory, 3 x uint64): */
+#define TCRC_CNT_MISMATCH 0  /* number of buffers whose checksum did not match */
+#define TCRC_CNT_FIRST_BAD 1 /* smallest index of a mismatching buffer, ~0 if none */
+#define TCRC_CNT_CHECKED 2   /* number of buffers checked */
+#define TCRC_CNT_WORDS 3
+
+/* ---- lifecycle ------------------------------------------------------------- */
+/* Creates an engine on GPU `device` (uploads the lookup tables).  Replaces the
+ * reference's static-init choice of implementation (util/crc32c.cc:1203-1225). */
+int tcrc_init(int device, tcrc_ctx** out);
+int tcrc_shutdown(tcrc_ctx* ctx);
+const char* tcrc_last_error(void);
+/* Text like the reference's IsFastCrc32Supported() (util/crc32c.cc:445-481). */
+const char* tcrc_describe(tcrc_ctx* ctx);
+
+/* ---- scalar helpers (host arithmetic on 32-bit values only) ------------------ */
+/* util/crc32c.h:38-47 */
+uint32_t tcrc_mask(uint32_t crc);
+uint32_t tcrc_unmask(uint32_t masked);
+
+/* ---- device-resident batches ------------------------------------------------ */
+/* n_blocks buffers of block_len bytes at d_base + i*stride, all with the same init
+ * and (if suffix_byte >= 0) one extra trailing byte covered by the CRC; d_suffix,
+ * when not NULL, gives that byte per block instead.  This is the SST trailer rule
+ * crc = Extend(Value(block), &type, 1); Mask(crc)
+ * (table/block_based_table_builder.cc:598-601) over a whole batch. */
+int tcrc_dev_blocks_stamp(tcrc_ctx* ctx, const void* d_base, uint64_t n_blocks, uint32_t block_len, uint64_t stride,
+                          uint32_t init, int suffix_byte, const uint8_t* d_suffix, uint32_t flags, uint32_t* d_out,
+                          void* stream);
+
+/* Same geometry, but compares against stored masked values: d_expected[i], or the
+ * in-image LE32 when TCRC_F_EXPECT_AFTER/_BEFORE is set.  Writes d_ok[i] = 1/0 when
+ * d_ok != NULL, the computed masked values when d_out != NULL, and accumulates
+ * d_counts (TCRC_CNT_*; zero/~0-initialise with tcrc_dev_counts_reset).  Batch form
+ * of BlockFetcher::CheckBlockChecksum (table/block_fetcher.cc:36-71). */
+int tcrc_dev_blocks_verify(tcrc_ctx* ctx, const void* d_base, uint64_t n_blocks, uint32_t block_len, uint64_t stride,
+                           uint32_t init, int suffix_byte, const uint8_t* d_suffix, uint32_t flags,
+                           const uint32_t* d_expected, uint32_t* d_out, uint8_t* d_ok, uint64_t* d_counts,
+                           void* stream);
+
+/* Arbitrary buffers described by d_desc[0..n).  Batch form of
+ * crc32c::Extend(init, data, n) (util/crc32c.cc:1226-1228), with the optional
+ * per-buffer suffix byte and Mask as above. */
+int tcrc_dev_batch_stamp(tcrc_ctx* ctx, const void* d_base, const tcrc_desc* d_desc, uint64_t n,
+                         const uint8_t* d_suffix, uint32_t flags, uint32_t* d_out, void* stream);
+int tcrc_dev_batch_verify(tcrc_ctx* ctx, const void* d_base, const tcrc_desc* d_desc, uint64_t n,
+                          const uint8_t* d_suffix, uint32_t flags, const uint32_t* d_expected, uint32_t* d_out,
+                          uint8_t* d_ok, uint64_t* d_counts, void* stream);
+
+/* Sets d_counts to {0, ~0, 0}. */
+int tcrc_dev_counts_reset(tcrc_ctx* ctx, uint64_t* d_counts, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TCRC_H_ */

@@ -1,0 +1,115 @@
+"""ctypes binding of libtcrc.so (declarations mirror include/tcrc.h)."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtcrc.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `make -C terarkdb_amd/csrc` (or __graft_entry__.build()). "
+        "The engine has no CPU fallback.")
+
+lib = C.CDLL(LIB_PATH)
+
+OK = 0
+ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_TOO_LARGE = -1, -2, -3, -4
+F_MASK, F_EXPECT_AFTER, F_EXPECT_BEFORE = 1, 2, 4
+CNT_MISMATCH, CNT_FIRST_BAD, CNT_CHECKED, CNT_WORDS = 0, 1, 2, 3
+
+
+class Desc(C.Structure):
+    _fields_ = [("offset", C.c_uint64), ("len", C.c_uint32), ("init", C.c_uint32)]
+
+
+_vp, _u64, _u32, _i = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
+SIGNATURES = {
+    "tcrc_init": (_i, [_i, C.POINTER(_vp)]),
+    "tcrc_shutdown": (_i, [_vp]),
+    "tcrc_last_error": (C.c_char_p, []),
+    "tcrc_describe": (C.c_char_p, [_vp]),
+    "tcrc_mask": (_u32, [_u32]),
+    "tcrc_unmask": (_u32, [_u32]),
+    "tcrc_dev_counts_reset": (_i, [_vp, _vp, _vp]),
+    "tcrc_dev_blocks_stamp": (_i, [_vp, _vp, _u64, _u32, _u64, _u32, _i, _vp, _u32, _vp, _vp]),
+    "tcrc_dev_blocks_verify": (_i, [_vp, _vp, _u64, _u32, _u64, _u32, _i, _vp, _u32, _vp, _vp, _vp, _vp, _vp]),
+    "tcrc_dev_batch_stamp": (_i, [_vp, _vp, _vp, _u64, _vp, _u32, _vp, _vp]),
+    "tcrc_dev_batch_verify": (_i, [_vp, _vp, _vp, _u64, _vp, _u32, _vp, _vp, _vp, _vp, _vp]),
+}
+for _name, (_res, _args) in SIGNATURES.items():
+    _f = getattr(lib, _name)
+    _f.restype = _res
+    _f.argtypes = _args
+
+
+class TcrcError(RuntimeError):
+    pass
+
+
+def check(rc):
+    if rc != OK:
+        raise TcrcError(f"tcrc error {rc}: {lib.tcrc_last_error().decode()}")
+
+
+def _dp(t):
+    """device pointer of a torch tensor (or None)"""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class Engine:
+    """One engine per GPU.  Tensors passed in must live on that GPU."""
+
+    def __init__(self, device=0):
+        self.ctx = C.c_void_p()
+        check(lib.tcrc_init(device, C.byref(self.ctx)))
+        self.device = device
+
+    def close(self):
+        if self.ctx:
+            lib.tcrc_shutdown(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def describe(self):
+        return lib.tcrc_describe(self.ctx).decode()
+
+    @staticmethod
+    def _stream(stream):
+        if stream is None:
+            import torch
+            return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        return C.c_void_p(stream)
+
+    def blocks_stamp(self, base, n_blocks, block_len, stride, out, init=0, suffix_byte=-1, suffix=None,
+                     flags=F_MASK, stream=None):
+        check(lib.tcrc_dev_blocks_stamp(self.ctx, _dp(base), n_blocks, block_len, stride, init, suffix_byte,
+                                        _dp(suffix), flags, _dp(out), self._stream(stream)))
+
+    def blocks_verify(self, base, n_blocks, block_len, stride, counts, expected=None, out=None, ok=None, init=0,
+                      suffix_byte=-1, suffix=None, flags=0, stream=None):
+        check(lib.tcrc_dev_blocks_verify(self.ctx, _dp(base), n_blocks, block_len, stride, init, suffix_byte,
+                                         _dp(suffix), flags, _dp(expected), _dp(out), _dp(ok), _dp(counts),
+                                         self._stream(stream)))
+
+    def batch_stamp(self, base, desc, n, out, suffix=None, flags=0, stream=None):
+        check(lib.tcrc_dev_batch_stamp(self.ctx, _dp(base), _dp(desc), n, _dp(suffix), flags, _dp(out),
+                                       self._stream(stream)))
+
+    def batch_verify(self, base, desc, n, counts, expected=None, out=None, ok=None, suffix=None, flags=0,
+                     stream=None):
+        check(lib.tcrc_dev_batch_verify(self.ctx, _dp(base), _dp(desc), n, _dp(suffix), flags, _dp(expected),
+                                        _dp(out), _dp(ok), _dp(counts), self._stream(stream)))
+
+    def counts_reset(self, counts, stream=None):
+        check(lib.tcrc_dev_counts_reset(self.ctx, _dp(counts), self._stream(stream)))
+
+
+def make_desc_tensor(offsets, lens, inits, device):
+    """Packs (offset u64, len u32, init u32) triples into a device tensor of tcrc_desc."""
+    import numpy as np
+    import torch
+    n = len(offsets)
+    a = np.zeros(n, dtype=[("offset", "<u8"), ("len", "<u4"), ("init", "<u4")])
+    a["offset"] = offsets
+    a["len"] = lens
+    a["init"] = inits
+    return torch.from_numpy(a.view(np.uint8).copy()).to(device)

@@ -1,0 +1,487 @@
+// tcrc engine: batched CRC-32C kernels for gfx950 and the C ABI around them.
+//
+// Algorithm (all arithmetic over GF(2), register convention of gf2.h):
+//   A buffer is walked by a group of G lanes.  One "row" is D = 16*G bytes; lane j
+//   owns the 16-byte column j of every row and keeps four independent 32-bit
+//   states, one per dword of its column.  Moving one row down is
+//       s_i <- Z_D(s_i) ^ w_i          (Z_D = advance through D zero bytes)
+//   and Z_D is four table lookups (one per state byte).  The tables live in LDS,
+//   replicated 32 times with the replica index in the bank bits, so that lane l
+//   only ever touches bank (l mod 32): every ds_read_b32 is conflict-free
+//   whatever the data is.  Rows are laid out so that the buffer ENDS on a row
+//   boundary; missing leading bytes are zeros, which do not change a CRC
+//   remainder, and the initial register is XORed into the first four message
+//   bytes.  After the last row the 4*G states are reduced to one register with
+//   log2(G)+4 more (unreplicated) table steps and wave shuffles.
+//   Loads are 16 bytes per lane, 128*G/8 contiguous bytes per group, so each
+//   wave instruction fetches whole 128-byte lines.
+//
+// What it computes is the reference's crc32c::Extend (util/crc32c.cc:356-398,
+// 1226-1228), Mask (util/crc32c.h:38-41), the SST trailer rule
+// (table/block_based_table_builder.cc:598-601) and the verify comparisons of
+// table/block_fetcher.cc:41-48,64 and db/log_reader.cc:388-390.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+
+#include "../../include/tcrc.h"
+#include "gf2.h"
+
+namespace {
+
+constexpr int kThreads = 1024;       // one workgroup per CU (LDS-bound), 16 waves
+constexpr int kWavesPerWg = kThreads / 64;
+constexpr int kMainDwords = 32768;   // 4 tables x 256 entries x 32 replicas
+constexpr uint32_t kMaskDelta = 0xa282ead8u;
+
+template <int G> struct Geo;
+template <> struct Geo<8>  { static constexpr int kLog2 = 3; };
+template <> struct Geo<16> { static constexpr int kLog2 = 4; };
+template <> struct Geo<64> { static constexpr int kLog2 = 6; };
+
+struct BatchParams {
+  const uint8_t* base;
+  const tcrc_desc* desc;  // NULL: uniform geometry below
+  uint64_t n;
+  uint64_t stride;
+  uint32_t block_len;
+  uint32_t uniform_init;
+  const uint8_t* suffix;   // per-buffer suffix byte, or NULL
+  int32_t uniform_suffix;  // >= 0: same suffix byte for all buffers
+  uint32_t flags;
+  uint32_t verify;         // 1: compare with expected
+  uint32_t* out;
+  const uint32_t* expected;
+  uint8_t* ok;
+  unsigned long long* counts;
+  const uint32_t* tab_main;  // 1024 dwords: Z_D set
+  const uint32_t* tab_aux;   // (1+log2 G) sets of 1024 dwords: Z_4, Z_16, Z_32, ...
+};
+
+__device__ __forceinline__ uint4 load16(const uint8_t* p) {
+  uint4 v;
+  __builtin_memcpy(&v, p, 16);  // unaligned global_load_dwordx4
+  return v;
+}
+
+// Z_D via the replicated tables; A = lds + (lane & 31).
+__device__ __forceinline__ uint32_t fold_main(const uint32_t* A, uint32_t c) {
+  return A[(c & 0xffu) * 32u] ^ A[8192u + ((c >> 8) & 0xffu) * 32u] ^ A[16384u + ((c >> 16) & 0xffu) * 32u] ^
+         A[24576u + (c >> 24) * 32u];
+}
+
+// Z_n via one unreplicated 4 KiB set.
+__device__ __forceinline__ uint32_t fold_aux(const uint32_t* t, uint32_t c) {
+  return t[c & 0xffu] ^ t[256u + ((c >> 8) & 0xffu)] ^ t[512u + ((c >> 16) & 0xffu)] ^ t[768u + (c >> 24)];
+}
+
+// The 16-byte column that starts m bytes into the message with -16 < m < 0: the
+// bytes before the message are zeros; the initial register r0 is XORed into
+// message bytes 0..3.
+__device__ __noinline__ uint4 load_straddle(const uint8_t* ptr, int m, uint32_t r0) {
+  uint32_t d[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int mo = m + k;
+    if (mo >= 0) {
+      uint32_t b = ptr[mo];
+      if (mo < 4) b ^= (r0 >> (8 * mo)) & 0xffu;
+      d[k >> 2] |= b << (8 * (k & 3));
+    }
+  }
+  return make_uint4(d[0], d[1], d[2], d[3]);
+}
+
+template <int G>
+__global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p) {
+  constexpr int D = 16 * G;
+  constexpr int LOG2G = Geo<G>::kLog2;
+  constexpr int GPW = 64 / G;  // groups (buffers) per wave
+  __shared__ uint32_t lds[kMainDwords + (1 + LOG2G) * 1024];
+
+  const int tid = threadIdx.x;
+  for (int i = tid; i < kMainDwords; i += kThreads) lds[i] = p.tab_main[i >> 5];
+  for (int i = tid; i < (1 + LOG2G) * 1024; i += kThreads) lds[kMainDwords + i] = p.tab_aux[i];
+  __syncthreads();
+
+  const int lane = tid & 63;
+  const int j = lane & (G - 1);
+  const int grp = lane / G;
+  const uint32_t* A = lds + (lane & 31);
+  const uint32_t* aux = lds + kMainDwords;
+  const uint64_t wave = (uint64_t)blockIdx.x * kWavesPerWg + (tid >> 6);
+  const uint64_t nwaves = (uint64_t)gridDim.x * kWavesPerWg;
+  const uint64_t nrounds = (p.n + GPW - 1) / GPW;
+
+  for (uint64_t round = wave; round < nrounds; round += nwaves) {
+    const uint64_t buf = round * GPW + grp;
+    const bool valid = buf < p.n;
+    uint64_t off = 0;
+    uint32_t len = 0, init = 0;
+    if (valid) {
+      if (p.desc) {
+        const tcrc_desc d = p.desc[buf];
+        off = d.offset;
+        len = d.len;
+        init = d.init;
+      } else {
+        off = buf * p.stride;
+        len = p.block_len;
+        init = p.uniform_init;
+      }
+    }
+    const uint32_t r0 = ~init;
+    const bool live = valid && len >= 4;  // shorter messages take the byte path at the end
+    const uint32_t elen = live ? len : 0u;
+    const uint32_t R = (elen + D - 1) / D;
+    uint32_t Rmax = R;
+#pragma unroll
+    for (int o = 32; o >= G; o >>= 1) {
+      const uint32_t other = __shfl_xor(Rmax, o);
+      Rmax = other > Rmax ? other : Rmax;
+    }
+    const uint8_t* ptr = p.base + off;
+    // message offset of this lane's column in row `it`: m0 + it*D
+    int m = (int)elen + 16 * j - (int)(Rmax * D);
+    uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    uint32_t it = 0;
+    const bool all_live = __all(live);
+
+#define TCRC_ROW(V_)                  \
+  do {                                \
+    s0 = fold_main(A, s0) ^ (V_).x;   \
+    s1 = fold_main(A, s1) ^ (V_).y;   \
+    s2 = fold_main(A, s2) ^ (V_).z;   \
+    s3 = fold_main(A, s3) ^ (V_).w;   \
+  } while (0)
+
+    // Rows in which some lane's column is not a plain full load.
+    while (it < Rmax) {
+      if (all_live && !__any(m < 4)) break;
+      uint4 w = make_uint4(0u, 0u, 0u, 0u);
+      if (live) {
+        if (m >= 0) {
+          w = load16(ptr + m);
+          if (m < 4) w.x ^= r0 >> (8 * m);
+        } else if (m > -16) {
+          w = load_straddle(ptr, m, r0);
+        }
+      }
+      TCRC_ROW(w);
+      m += D;
+      ++it;
+    }
+    // Steady state: every lane loads a full column.
+    if (it < Rmax) {
+      const uint8_t* q = ptr + m;
+      uint32_t left = Rmax - it;
+      while (left >= 4) {
+        const uint4 a = load16(q);
+        const uint4 b = load16(q + D);
+        const uint4 c = load16(q + 2 * D);
+        const uint4 d = load16(q + 3 * D);
+        q += 4 * D;
+        TCRC_ROW(a);
+        TCRC_ROW(b);
+        TCRC_ROW(c);
+        TCRC_ROW(d);
+        left -= 4;
+      }
+      while (left) {
+        const uint4 a = load16(q);
+        q += D;
+        TCRC_ROW(a);
+        --left;
+      }
+    }
+#undef TCRC_ROW
+
+    // Column states -> one value per lane (bytes j*16 .. j*16+15 of the last row).
+    uint32_t u = fold_aux(aux, s0) ^ s1;
+    u = fold_aux(aux, u) ^ s2;
+    u = fold_aux(aux, u) ^ s3;
+    // Lanes -> lane G-1: at step d lanes [G-2d, G-d) hand Z_{16d}(u) to [G-d, G).
+#pragma unroll
+    for (int st = LOG2G; st >= 1; --st) {
+      const int d = 1 << (st - 1);
+      const uint32_t t = fold_aux(aux + st * 1024, u);
+      u ^= __shfl_up(t, d, G);
+    }
+
+    if (valid && j == G - 1) {
+      uint32_t r;
+      if (live) {
+        r = fold_aux(aux, u);  // the last dword still owes its own four bytes
+      } else {
+        r = r0;
+        const uint32_t* T0 = aux + 768;  // one-byte step table
+        for (uint32_t k = 0; k < len; ++k) r = T0[(r ^ ptr[k]) & 0xffu] ^ (r >> 8);
+      }
+      int sfx = p.uniform_suffix;
+      if (p.suffix) sfx = p.suffix[buf];
+      if (sfx >= 0) r = aux[768u + ((r ^ (uint32_t)sfx) & 0xffu)] ^ (r >> 8);
+      const uint32_t crc = ~r;
+      const uint32_t masked = ((crc >> 15) | (crc << 17)) + kMaskDelta;
+      if (p.out) p.out[buf] = (p.flags & TCRC_F_MASK) ? masked : crc;
+      if (p.verify) {
+        uint32_t stored;
+        if (p.expected) {
+          stored = p.expected[buf];
+        } else {
+          const uint8_t* e = (p.flags & TCRC_F_EXPECT_AFTER) ? ptr + len : ptr - 6;
+          stored = (uint32_t)e[0] | ((uint32_t)e[1] << 8) | ((uint32_t)e[2] << 16) | ((uint32_t)e[3] << 24);
+        }
+        const bool good = stored == masked;
+        if (p.ok) p.ok[buf] = good ? 1 : 0;
+        if (!good) {
+          atomicAdd(&p.counts[TCRC_CNT_MISMATCH], 1ull);
+          atomicMin(&p.counts[TCRC_CNT_FIRST_BAD], (unsigned long long)buf);
+        }
+      }
+    }
+  }
+  if (p.verify && blockIdx.x == 0 && tid == 0) atomicAdd(&p.counts[TCRC_CNT_CHECKED], (unsigned long long)p.n);
+}
+
+__global__ void k_counts_reset(unsigned long long* c) {
+  c[TCRC_CNT_MISMATCH] = 0ull;
+  c[TCRC_CNT_FIRST_BAD] = ~0ull;
+  c[TCRC_CNT_CHECKED] = 0ull;
+}
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess)                                                                     \
+      return fail(TCRC_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));           \
+  } while (0)
+
+constexpr int kGeoCount = 3;
+constexpr int kGeoLanes[kGeoCount] = {8, 16, 64};
+
+}  // namespace
+
+struct tcrc_ctx {
+  int device = -1;
+  int cus = 0;
+  int forced_g = 0;
+  uint32_t* d_tab_main[kGeoCount] = {nullptr, nullptr, nullptr};
+  uint32_t* d_tab_aux[kGeoCount] = {nullptr, nullptr, nullptr};
+  std::string description;
+};
+
+namespace {
+
+int geo_index(int g) {
+  for (int i = 0; i < kGeoCount; ++i)
+    if (kGeoLanes[i] == g) return i;
+  return -1;
+}
+
+template <int G>
+int launch_batch(tcrc_ctx* ctx, BatchParams p, hipStream_t s) {
+  const int gi = geo_index(G);
+  p.tab_main = ctx->d_tab_main[gi];
+  p.tab_aux = ctx->d_tab_aux[gi];
+  const uint64_t rounds = (p.n + (64 / G) - 1) / (64 / G);
+  uint64_t wgs = (rounds + kWavesPerWg - 1) / kWavesPerWg;
+  if (wgs > (uint64_t)ctx->cus) wgs = (uint64_t)ctx->cus;
+  if (wgs == 0) wgs = 1;
+  hipLaunchKernelGGL(k_crc_batch<G>, dim3((unsigned)wgs), dim3(kThreads), 0, s, p);
+  HIP_TRY(hipGetLastError());
+  return TCRC_OK;
+}
+
+int run_batch(tcrc_ctx* ctx, BatchParams p, uint32_t typical_len, void* stream) {
+  if (!ctx) return fail(TCRC_ERR_INVALID, "null context");
+  if (p.n == 0) return TCRC_OK;
+  if (!p.base) return fail(TCRC_ERR_INVALID, "null base pointer");
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t s = (hipStream_t)stream;
+  int g = ctx->forced_g;
+  if (g == 0) g = 8;
+  (void)typical_len;
+  switch (g) {
+    case 8: return launch_batch<8>(ctx, p, s);
+    case 16: return launch_batch<16>(ctx, p, s);
+    case 64: return launch_batch<64>(ctx, p, s);
+    default: return fail(TCRC_ERR_INVALID, "unsupported lanes-per-buffer setting");
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* tcrc_last_error(void) { return g_err.c_str(); }
+
+uint32_t tcrc_mask(uint32_t crc) { return ((crc >> 15) | (crc << 17)) + kMaskDelta; }
+uint32_t tcrc_unmask(uint32_t masked) {
+  const uint32_t rot = masked - kMaskDelta;
+  return (rot >> 17) | (rot << 15);
+}
+
+int tcrc_init(int device, tcrc_ctx** out) {
+  if (!out) return fail(TCRC_ERR_INVALID, "null out pointer");
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+    return fail(TCRC_ERR_NO_DEVICE, "no HIP device available: the tcrc engine has no CPU fallback");
+  if (device < 0 || device >= count) return fail(TCRC_ERR_INVALID, "device index out of range");
+  HIP_TRY(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  tcrc_ctx* ctx = new tcrc_ctx();
+  ctx->device = device;
+  ctx->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (const char* e = getenv("TCRC_LANES_PER_BUFFER")) ctx->forced_g = atoi(e);
+  for (int gi = 0; gi < kGeoCount; ++gi) {
+    const int G = kGeoLanes[gi];
+    int log2g = 0;
+    while ((1 << log2g) < G) ++log2g;
+    uint32_t t[4][256];
+    tcrc::build_shift_tables(16u * G, t);
+    hipError_t e = hipMalloc(&ctx->d_tab_main[gi], sizeof(t));
+    if (e == hipSuccess) e = hipMemcpy(ctx->d_tab_main[gi], t, sizeof(t), hipMemcpyHostToDevice);
+    const size_t aux_bytes = (size_t)(1 + log2g) * sizeof(t);
+    uint32_t* aux = (uint32_t*)malloc(aux_bytes);
+    tcrc::build_shift_tables(4, t);
+    memcpy(aux, t, sizeof(t));
+    for (int st = 1; st <= log2g; ++st) {
+      tcrc::build_shift_tables(16u << (st - 1), t);
+      memcpy(aux + st * 1024, t, sizeof(t));
+    }
+    if (e == hipSuccess) e = hipMalloc(&ctx->d_tab_aux[gi], aux_bytes);
+    if (e == hipSuccess) e = hipMemcpy(ctx->d_tab_aux[gi], aux, aux_bytes, hipMemcpyHostToDevice);
+    free(aux);
+    if (e != hipSuccess) {
+      tcrc_shutdown(ctx);
+      return fail(TCRC_ERR_HIP, std::string("table upload: ") + hipGetErrorString(e));
+    }
+  }
+  char buf[256];
+  snprintf(buf, sizeof(buf), "Supported on %s (%s, %d CUs): LDS-table batched CRC32C", prop.name, prop.gcnArchName,
+           ctx->cus);
+  ctx->description = buf;
+  *out = ctx;
+  return TCRC_OK;
+}
+
+int tcrc_shutdown(tcrc_ctx* ctx) {
+  if (!ctx) return TCRC_OK;
+  (void)hipSetDevice(ctx->device);
+  for (int gi = 0; gi < kGeoCount; ++gi) {
+    if (ctx->d_tab_main[gi]) (void)hipFree(ctx->d_tab_main[gi]);
+    if (ctx->d_tab_aux[gi]) (void)hipFree(ctx->d_tab_aux[gi]);
+  }
+  delete ctx;
+  return TCRC_OK;
+}
+
+const char* tcrc_describe(tcrc_ctx* ctx) { return ctx ? ctx->description.c_str() : "no context"; }
+
+int tcrc_dev_counts_reset(tcrc_ctx* ctx, uint64_t* d_counts, void* stream) {
+  if (!ctx || !d_counts) return fail(TCRC_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(k_counts_reset, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)d_counts);
+  HIP_TRY(hipGetLastError());
+  return TCRC_OK;
+}
+
+static int check_uniform(uint64_t n_blocks, uint32_t block_len, uint64_t stride) {
+  if (block_len > (1u << 30)) return fail(TCRC_ERR_TOO_LARGE, "block_len above 1 GiB: use the long-buffer entry point");
+  if (n_blocks > 1 && stride < block_len) return fail(TCRC_ERR_INVALID, "stride smaller than block_len");
+  return TCRC_OK;
+}
+
+int tcrc_dev_blocks_stamp(tcrc_ctx* ctx, const void* d_base, uint64_t n_blocks, uint32_t block_len, uint64_t stride,
+                          uint32_t init, int suffix_byte, const uint8_t* d_suffix, uint32_t flags, uint32_t* d_out,
+                          void* stream) {
+  if (int rc = check_uniform(n_blocks, block_len, stride)) return rc;
+  if (!d_out && n_blocks) return fail(TCRC_ERR_INVALID, "null output pointer");
+  BatchParams p{};
+  p.base = (const uint8_t*)d_base;
+  p.n = n_blocks;
+  p.stride = stride;
+  p.block_len = block_len;
+  p.uniform_init = init;
+  p.suffix = d_suffix;
+  p.uniform_suffix = suffix_byte >= 0 ? (suffix_byte & 0xff) : -1;
+  p.flags = flags;
+  p.out = d_out;
+  return run_batch(ctx, p, block_len, stream);
+}
+
+int tcrc_dev_blocks_verify(tcrc_ctx* ctx, const void* d_base, uint64_t n_blocks, uint32_t block_len, uint64_t stride,
+                           uint32_t init, int suffix_byte, const uint8_t* d_suffix, uint32_t flags,
+                           const uint32_t* d_expected, uint32_t* d_out, uint8_t* d_ok, uint64_t* d_counts,
+                           void* stream) {
+  if (int rc = check_uniform(n_blocks, block_len, stride)) return rc;
+  if (!d_counts) return fail(TCRC_ERR_INVALID, "verify needs a counts block");
+  if (!d_expected && !(flags & (TCRC_F_EXPECT_AFTER | TCRC_F_EXPECT_BEFORE)))
+    return fail(TCRC_ERR_INVALID, "verify needs d_expected or an in-image expectation flag");
+  BatchParams p{};
+  p.base = (const uint8_t*)d_base;
+  p.n = n_blocks;
+  p.stride = stride;
+  p.block_len = block_len;
+  p.uniform_init = init;
+  p.suffix = d_suffix;
+  p.uniform_suffix = suffix_byte >= 0 ? (suffix_byte & 0xff) : -1;
+  p.flags = flags | TCRC_F_MASK;
+  p.verify = 1;
+  p.out = d_out;
+  p.expected = d_expected;
+  p.ok = d_ok;
+  p.counts = (unsigned long long*)d_counts;
+  return run_batch(ctx, p, block_len, stream);
+}
+
+int tcrc_dev_batch_stamp(tcrc_ctx* ctx, const void* d_base, const tcrc_desc* d_desc, uint64_t n,
+                         const uint8_t* d_suffix, uint32_t flags, uint32_t* d_out, void* stream) {
+  if (n && (!d_desc || !d_out)) return fail(TCRC_ERR_INVALID, "null descriptor or output pointer");
+  BatchParams p{};
+  p.base = (const uint8_t*)d_base;
+  p.desc = d_desc;
+  p.n = n;
+  p.suffix = d_suffix;
+  p.uniform_suffix = -1;
+  p.flags = flags;
+  p.out = d_out;
+  return run_batch(ctx, p, 0, stream);
+}
+
+int tcrc_dev_batch_verify(tcrc_ctx* ctx, const void* d_base, const tcrc_desc* d_desc, uint64_t n,
+                          const uint8_t* d_suffix, uint32_t flags, const uint32_t* d_expected, uint32_t* d_out,
+                          uint8_t* d_ok, uint64_t* d_counts, void* stream) {
+  if (n && !d_desc) return fail(TCRC_ERR_INVALID, "null descriptor pointer");
+  if (!d_counts) return fail(TCRC_ERR_INVALID, "verify needs a counts block");
+  if (!d_expected && !(flags & (TCRC_F_EXPECT_AFTER | TCRC_F_EXPECT_BEFORE)))
+    return fail(TCRC_ERR_INVALID, "verify needs d_expected or an in-image expectation flag");
+  BatchParams p{};
+  p.base = (const uint8_t*)d_base;
+  p.desc = d_desc;
+  p.n = n;
+  p.suffix = d_suffix;
+  p.uniform_suffix = -1;
+  p.flags = flags | TCRC_F_MASK;
+  p.verify = 1;
+  p.out = d_out;
+  p.expected = d_expected;
+  p.ok = d_ok;
+  p.counts = (unsigned long long*)d_counts;
+  return run_batch(ctx, p, 0, stream);
+}
+
+}  // extern "C"

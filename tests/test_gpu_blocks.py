@@ -1,0 +1,164 @@
+"""GPU parity: the HIP path through the C ABI against the CPU oracle, bit for bit."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+CAP = json.load(open(os.path.join(HERE, "golden", "reference_captured.json")))
+
+
+@pytest.fixture(scope="module", params=[8, 16, 64])
+def eng(request):
+    import gpu_util as G
+    e = G.engine(request.param)
+    yield e
+    e.close()
+
+
+def test_splitmix_generator_matches_oracle():
+    import gpu_util as G
+    d = G.splitmix_dev(1 << 20).cpu().numpy()
+    assert bytes(d[:16]).hex() == CAP["splitmix_first16_hex"]
+    assert (d == O.splitmix(1 << 20)).all()
+
+
+def test_uniform_8k_blocks_with_type_byte(eng):
+    import gpu_util as G
+    import terarkdb_amd.capi as capi
+    n, blen = 4099, 8192  # not a multiple of the wave's buffers-per-round
+    host = O.splitmix(n * blen, 301)
+    dev = G.to_dev(host)
+    out = torch.zeros(n, dtype=torch.int32, device="cuda")
+    eng.blocks_stamp(dev, n, blen, blen, out, suffix_byte=0, flags=capi.F_MASK)
+    torch.cuda.synchronize()
+    want = O.sst_trailer_batch(host, blen, blen, n, 0)
+    got = out.cpu().numpy().view(np.uint32)
+    assert (got == want).all()
+    # the captured value for the first block: Value(S[:8193]) has type byte 0 == next stream byte? no: check 8192 prefix
+    first = O.mask(O.extend(int(dict((a, b) for a, b in CAP["value_of_S_prefix"])[8192], 16), b"\0"))
+    assert int(got[0]) == first
+
+
+@pytest.mark.parametrize("blen,stride", [(4096, 4101), (8192, 8197), (1000, 1000), (16, 16), (129, 131), (5, 9),
+                                         (32761, 32768), (65536 + 3, 65536 + 8)])
+def test_uniform_other_geometries(eng, blen, stride):
+    import gpu_util as G
+    import terarkdb_amd.capi as capi
+    n = max(3, min(700, (6 << 20) // stride))
+    host = O.splitmix(((n * stride + 64) // 8) * 8, 17)
+    dev = G.to_dev(host)
+    out = torch.zeros(n, dtype=torch.int32, device="cuda")
+    eng.blocks_stamp(dev, n, blen, stride, out, init=0x1234abcd, suffix_byte=-1, flags=0)
+    torch.cuda.synchronize()
+    offs = np.arange(n, dtype=np.uint64) * stride
+    want = O.batch_extend(host, offs, np.full(n, blen, np.uint32), np.full(n, 0x1234abcd, np.uint32))
+    assert (out.cpu().numpy().view(np.uint32) == want).all()
+
+
+def test_descriptor_batch_ragged(eng):
+    import gpu_util as G
+    import terarkdb_amd.capi as capi
+    rng = np.random.default_rng(11)
+    total = 8 << 20
+    host = rng.integers(0, 256, size=total, dtype=np.uint8)
+    lens = np.concatenate([
+        np.arange(0, 300),                      # every tiny length, empty included
+        rng.integers(0, 5000, size=1500),
+        np.array([127, 128, 129, 255, 256, 257, 1023, 1024, 1025, 8192, 8193, 32761, 65535, 65536, 100000]),
+    ]).astype(np.uint32)
+    rng.shuffle(lens)
+    n = lens.size
+    offs = rng.integers(0, total - 100001, size=n).astype(np.uint64)
+    inits = rng.integers(0, 2**32, size=n, dtype=np.uint64).astype(np.uint32)
+    inits[::3] = 0
+    suffix = rng.integers(0, 256, size=n, dtype=np.uint8)
+    dev = G.to_dev(host)
+    desc = capi.make_desc_tensor(offs, lens, inits, "cuda")
+    out = torch.zeros(n, dtype=torch.int32, device="cuda")
+    # plain Extend
+    eng.batch_stamp(dev, desc, n, out, flags=0)
+    torch.cuda.synchronize()
+    want = O.batch_extend(host, offs, lens, inits)
+    got = out.cpu().numpy().view(np.uint32)
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, (bad[:10], lens[bad[:10]], offs[bad[:10]] % 16)
+    # with suffix byte and Mask
+    eng.batch_stamp(dev, desc, n, out, suffix=G.to_dev(suffix), flags=capi.F_MASK)
+    torch.cuda.synchronize()
+    want = O.batch_extend(host, offs, lens, inits, suffix, masked=True)
+    assert (out.cpu().numpy().view(np.uint32) == want).all()
+
+
+def test_reference_known_answers_on_device(eng):
+    """util/crc32c_test.cc's table (offset, length, ~crc) over the FNV-chained buffer, one-shot and stitched."""
+    import gpu_util as G
+    import terarkdb_amd.capi as capi
+    ka = json.load(open(os.path.join(HERE, "golden", "crc32c_known_answers.json")))
+    host = O.fnv_chain(ka["fnv_chain_buffer_size"])
+    dev = G.to_dev(host)
+    rows = ka["fnv_chain"]
+    n = len(rows)
+    offs = np.array([r[0] for r in rows], np.uint64)
+    lens = np.array([r[1] for r in rows], np.uint32)
+    want = np.array([(~r[2]) & 0xffffffff for r in rows], np.uint32)
+    out = torch.zeros(n, dtype=torch.int32, device="cuda")
+    eng.batch_stamp(dev, capi.make_desc_tensor(offs, lens, np.zeros(n, np.uint32), "cuda"), n, out)
+    torch.cuda.synchronize()
+    assert (out.cpu().numpy().view(np.uint32) == want).all()
+    # stitched: Extend(Value(first half), second half)
+    half = lens // 2
+    eng.batch_stamp(dev, capi.make_desc_tensor(offs, half, np.zeros(n, np.uint32), "cuda"), n, out)
+    torch.cuda.synchronize()
+    part = out.cpu().numpy().view(np.uint32).copy()
+    eng.batch_stamp(dev, capi.make_desc_tensor(offs + half, lens - half, part, "cuda"), n, out)
+    torch.cuda.synchronize()
+    assert (out.cpu().numpy().view(np.uint32) == want).all()
+    # RFC 3720 vectors
+    for v in ka["rfc3720"]:
+        b = np.frombuffer(bytes.fromhex(v["hex"]), np.uint8)
+        d = G.to_dev(b)
+        o1 = torch.zeros(1, dtype=torch.int32, device="cuda")
+        eng.blocks_stamp(d, 1, b.size, b.size, o1, flags=0)
+        torch.cuda.synchronize()
+        assert int(o1.cpu().numpy().view(np.uint32)[0]) == int(v["crc"], 16), v["name"]
+
+
+def test_verify_counts_and_first_bad(eng):
+    import gpu_util as G
+    import terarkdb_amd.capi as capi
+    n, blen = 2000, 4096
+    stride = blen + 5
+    img = np.zeros(n * stride, np.uint8)
+    data = O.splitmix(n * blen, 99).reshape(n, blen)
+    view = img.reshape(n, stride)
+    view[:, :blen] = data
+    view[:, blen] = 0  # type byte
+    tr = O.batch_extend(img, np.arange(n, dtype=np.uint64) * stride, np.full(n, blen + 1, np.uint32), None, None, True)
+    view[:, blen + 1:] = tr.view(np.uint8).reshape(n, 4)
+    bad = [1500, 37, 999]
+    for b in bad:
+        view[b, 100] ^= 0x80
+    dev = G.to_dev(img)
+    counts = torch.zeros(3, dtype=torch.int64, device="cuda")
+    ok = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    eng.counts_reset(counts)
+    # CheckBlockChecksum shape: Value(data, size + 1) against the LE32 after it
+    eng.blocks_verify(dev, n, blen + 1, stride, counts, ok=ok, flags=capi.F_EXPECT_AFTER)
+    torch.cuda.synchronize()
+    c = counts.cpu().numpy().view(np.uint64)
+    assert int(c[capi.CNT_MISMATCH]) == 3 and int(c[capi.CNT_FIRST_BAD]) == 37 and int(c[capi.CNT_CHECKED]) == n
+    okh = ok.cpu().numpy()
+    assert sorted(np.nonzero(okh == 0)[0].tolist()) == sorted(bad)
+    # same through an explicit expected array and the suffix-byte form
+    exp = G.to_dev(tr)
+    eng.counts_reset(counts)
+    eng.blocks_verify(dev, n, blen, stride, counts, expected=exp, ok=ok, suffix_byte=0)
+    torch.cuda.synchronize()
+    c = counts.cpu().numpy().view(np.uint64)
+    assert int(c[capi.CNT_MISMATCH]) == 3 and int(c[capi.CNT_FIRST_BAD]) == 37
