@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""Headline benchmark: device-resident masked CRC32C over a 1 GiB batch of 8 KiB SST blocks.
+
+One "step" = one pass of the hot path over the batch: a single tcrc_dev_blocks_verify launch
+that computes Mask(CRC32C(block || type)) for every block, stores it and compares it with
+the stored trailer value.  Inputs are resident in HBM before the timed region.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+With N > 1 every rank owns one GPU and one 1 GiB shard of the corpus (block-range sharding,
+weak scaling); no data moves between GPUs, and the only collective is one all-reduce (RCCL)
+of {mismatches, blocks checked} inside the timed region.
+
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+BLOCK_LEN = 8192
+N_BLOCKS = 131072            # 1 GiB
+TYPE_BYTE = 0                # kNoCompression
+SPLITMIX_STATE = 301
+XOR_OF_MASKED = 0x0744A84E   # fold of all trailers of this corpus, captured from a build of the reference
+N_CORRUPT = 5                # seeded single-bit corruptions per shard (verification must find exactly these)
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E peak
+
+
+def cpu_baseline(seconds_budget=12.0):
+    """The CPU oracle's SSE4.2+PCLMUL path on the same workload, timed on this host.
+    Checker code (oracle/) is used here only as the thing a GPU number is shown beside."""
+    import oracle_lib as O
+    L = O.lib()
+    cores = max(1, min(16, len(os.sched_getaffinity(0))))
+    sample_blocks = 32768  # 256 MiB of the same stream
+    buf = O.splitmix(sample_blocks * BLOCK_LEN, SPLITMIX_STATE)
+    out = np.empty(sample_blocks, dtype=np.uint32)
+    hw = int(L.oracle_crc32c_hw_available())
+
+    def run(nthreads, passes):
+        per = sample_blocks // nthreads
+
+        def work(t):
+            base = buf.ctypes.data + t * per * BLOCK_LEN
+            o = out.ctypes.data + t * per * 4
+            for _ in range(passes):
+                L.oracle_sst_trailer_batch(C.c_void_p(base), BLOCK_LEN, BLOCK_LEN, per, TYPE_BYTE, hw, C.c_void_p(o))
+
+        ths = [threading.Thread(target=work, args=(t,)) for t in range(nthreads)]
+        t0 = time.perf_counter()
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        return time.perf_counter() - t0
+
+    run(1, 1)  # warm
+    t1 = run(1, 2)
+    single = 2 * sample_blocks * (BLOCK_LEN + 1) / t1 / 1e9
+    passes = max(2, int(seconds_budget * 0.6 / max(t1 / 2 / cores, 1e-3) / 1.0))
+    passes = min(passes, 200)
+    tn = run(cores, passes)
+    multi = passes * (sample_blocks // cores) * cores * (BLOCK_LEN + 1) / tn / 1e9
+    return {
+        "value": round(multi, 2), "unit": "GB/s", "cores": cores, "kind": "port",
+        "single_core_value": round(single, 2),
+        "sample": f"{sample_blocks} x {BLOCK_LEN} B blocks (256 MiB of the same splitmix stream), "
+                  f"{passes} passes on {cores} threads, static block-range split; "
+                  f"oracle SSE4.2 crc32 + PCLMUL 3-way path (hw={hw})",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+
+    import gpu_util as G
+    import terarkdb_amd.capi as capi
+    import oracle_lib as O
+
+    eng = capi.Engine(local_rank)
+    # every rank checks its own shard of the corpus: shard r is the stream with state 301 + r
+    state = SPLITMIX_STATE + rank
+    data = G.splitmix_dev(N_BLOCKS * BLOCK_LEN, state)
+    stored = torch.zeros(N_BLOCKS, dtype=torch.int32, device="cuda")
+    out = torch.zeros(N_BLOCKS, dtype=torch.int32, device="cuda")
+    counts = torch.zeros(capi.CNT_WORDS, dtype=torch.int64, device="cuda")
+
+    # -- parity gate (untimed): stamp, compare with the CPU oracle, then seed corruptions ------------
+    eng.blocks_stamp(data, N_BLOCKS, BLOCK_LEN, BLOCK_LEN, stored, suffix_byte=TYPE_BYTE, flags=capi.F_MASK)
+    torch.cuda.synchronize()
+    host_tr = stored.cpu().numpy().view(np.uint32)
+    if rank == 0:
+        fold = int(np.bitwise_xor.reduce(host_tr))
+        if fold != XOR_OF_MASKED:
+            raise SystemExit(f"parity gate failed: xor of trailers {fold:08x} != {XOR_OF_MASKED:08x}")
+    sample_idx = np.unique(np.concatenate([np.arange(0, 64), np.arange(N_BLOCKS - 64, N_BLOCKS),
+                                           np.random.default_rng(rank).integers(0, N_BLOCKS, 512)]))
+    blocks = data.view(N_BLOCKS, BLOCK_LEN)[torch.from_numpy(sample_idx).cuda()].cpu().numpy()
+    want = O.sst_trailer_batch(blocks, BLOCK_LEN, BLOCK_LEN, len(sample_idx), TYPE_BYTE)
+    if not (want == host_tr[sample_idx]).all():
+        raise SystemExit("parity gate failed: device trailers differ from the CPU oracle")
+    bad_blocks = np.sort(np.random.default_rng(1000 + rank).choice(N_BLOCKS, N_CORRUPT, replace=False))
+    flat = data.view(-1)
+    for b in bad_blocks:
+        flat[int(b) * BLOCK_LEN + 100] ^= 0x80
+    torch.cuda.synchronize()
+
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        eng.blocks_verify(data, N_BLOCKS, BLOCK_LEN, BLOCK_LEN, counts, expected=stored, out=out,
+                          suffix_byte=TYPE_BYTE, stream=stream)
+
+    for _ in range(args.warmup):
+        step()
+    # touch every other op of the timed region once, so no first-use set-up cost lands inside it
+    warm = counts[[capi.CNT_MISMATCH, capi.CNT_CHECKED]].clone()
+    if dist:
+        dist.all_reduce(warm)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    e1.record()
+    eng.counts_reset(counts)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record()   # the kernel is enqueued on torch's current stream, so these events bracket it
+        step()
+        b.record()
+    totals = counts[[capi.CNT_MISMATCH, capi.CNT_CHECKED]].clone()
+    if dist:
+        dist.all_reduce(totals)  # the path's only collective: 16 bytes over RCCL
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    mism, checked = int(totals[0].item()), int(totals[1].item())
+    first_bad = int(counts.cpu().numpy().view(np.uint64)[capi.CNT_FIRST_BAD])
+    if mism != N_CORRUPT * args.steps * world or checked != N_BLOCKS * args.steps * world:
+        raise SystemExit(f"verification miscounted: {mism} mismatches / {checked} checked")
+    if first_bad != int(bad_blocks[0]):
+        raise SystemExit(f"first bad block {first_bad} != {int(bad_blocks[0])}")
+
+    kernel_ms = sorted(a.elapsed_time(b) for a, b in ev)
+    avg_ms = sum(kernel_ms) / len(kernel_ms)
+    alg_bytes = N_BLOCKS * (BLOCK_LEN + 1)  # bytes covered by the CRC: block + type byte
+    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+    value = world * args.steps * alg_bytes / elapsed / 1e9
+
+    if rank == 0:
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "device-resident masked-CRC32C GB/s, 8 KiB blocks",
+            "value": round(value, 1), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": "1 GiB batch of 8 KiB SST data blocks per GPU (131072 blocks, type byte 0): "
+                                   "masked CRC32C stamped and verified against stored trailers",
+                       "block_len": BLOCK_LEN, "blocks_per_gpu": N_BLOCKS, "sharding": "block range per GPU",
+                       "collective": "one all-reduce of {mismatches, checked}" if world > 1 else "none"},
+            "pct_hbm_peak": round(100.0 * value / (HBM_PEAK_GBS * world), 2),
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel": "k_crc_batch", "avg_launch_ms": round(avg_ms, 4),
+                         "median_launch_ms": round(kernel_ms[len(kernel_ms) // 2], 4),
+                         "algorithmic_bytes_per_launch": alg_bytes},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    eng.close()
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

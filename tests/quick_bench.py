@@ -5,7 +5,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, "tests")
+sys.path.insert(0, "tests"); sys.path.insert(0, ".")
 import gpu_util as G
 import terarkdb_amd.capi as capi
 
