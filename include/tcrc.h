@@ -98,6 +98,13 @@ int tcrc_dev_batch_verify(tcrc_ctx* ctx, const void* d_base, const tcrc_desc* d_
 /* Sets d_counts to {0, ~0, 0}. */
 int tcrc_dev_counts_reset(tcrc_ctx* ctx, uint64_t* d_counts, void* stream);
 
+/* ---- measurement aid ----------------------------------------------------------- */
+/* Streams nbytes from d_base with loads only (no checksum work) so a benchmark can report
+ * the read rate this device actually reaches beside the CRC kernels' rate.  d_scratch
+ * must hold 2 * 1024 * (number of CUs) uint32.  No counterpart in the reference. */
+int tcrc_dev_probe_read(tcrc_ctx* ctx, const void* d_base, uint64_t nbytes, uint32_t* d_scratch, uint32_t wgs_per_cu,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif

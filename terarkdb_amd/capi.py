@@ -31,6 +31,7 @@ SIGNATURES = {
     "tcrc_mask": (_u32, [_u32]),
     "tcrc_unmask": (_u32, [_u32]),
     "tcrc_dev_counts_reset": (_i, [_vp, _vp, _vp]),
+    "tcrc_dev_probe_read": (_i, [_vp, _vp, _u64, _vp, _u32, _vp]),
     "tcrc_dev_blocks_stamp": (_i, [_vp, _vp, _u64, _u32, _u64, _u32, _i, _vp, _u32, _vp, _vp]),
     "tcrc_dev_blocks_verify": (_i, [_vp, _vp, _u64, _u32, _u64, _u32, _i, _vp, _u32, _vp, _vp, _vp, _vp, _vp]),
     "tcrc_dev_batch_stamp": (_i, [_vp, _vp, _vp, _u64, _vp, _u32, _vp, _vp]),
@@ -98,6 +99,9 @@ class Engine:
                      stream=None):
         check(lib.tcrc_dev_batch_verify(self.ctx, _dp(base), _dp(desc), n, _dp(suffix), flags, _dp(expected),
                                         _dp(out), _dp(ok), _dp(counts), self._stream(stream)))
+
+    def probe_read(self, base, nbytes, scratch, wgs_per_cu=1, stream=None):
+        check(lib.tcrc_dev_probe_read(self.ctx, _dp(base), nbytes, _dp(scratch), wgs_per_cu, self._stream(stream)))
 
     def counts_reset(self, counts, stream=None):
         check(lib.tcrc_dev_counts_reset(self.ctx, _dp(counts), self._stream(stream)))

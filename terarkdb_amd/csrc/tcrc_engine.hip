@@ -62,10 +62,20 @@ struct BatchParams {
   const uint32_t* tab_aux;   // (1+log2 G) sets of 1024 dwords: Z_4, Z_16, Z_32, ...
 };
 
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+typedef v4u v4u_any __attribute__((aligned(1)));
+
+// 16 bytes from any address: one global_load_dwordx4 (gfx950 handles unaligned vector loads).
+// NT marks the line as streamed-once.
+template <bool NT>
 __device__ __forceinline__ uint4 load16(const uint8_t* p) {
-  uint4 v;
-  __builtin_memcpy(&v, p, 16);  // unaligned global_load_dwordx4
-  return v;
+  v4u v;
+  if (NT) {
+    v = __builtin_nontemporal_load((const v4u_any*)p);
+  } else {
+    v = *(const v4u_any*)p;
+  }
+  return make_uint4(v.x, v.y, v.z, v.w);
 }
 
 // Z_D via the replicated tables; A = lds + (lane & 31).
@@ -96,7 +106,7 @@ __device__ __noinline__ uint4 load_straddle(const uint8_t* ptr, int m, uint32_t 
   return make_uint4(d[0], d[1], d[2], d[3]);
 }
 
-template <int G>
+template <int G, bool NT>
 __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p) {
   constexpr int D = 16 * G;
   constexpr int LOG2G = Geo<G>::kLog2;
@@ -134,6 +144,16 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p) {
         init = p.uniform_init;
       }
     }
+    // the stored value is fetched now so its latency hides behind the row loop
+    uint32_t stored = 0;
+    if (p.verify && valid && j == G - 1) {
+      if (p.expected) {
+        stored = p.expected[buf];
+      } else {
+        const uint8_t* e = (p.flags & TCRC_F_EXPECT_AFTER) ? p.base + off + len : p.base + off - 6;
+        stored = (uint32_t)e[0] | ((uint32_t)e[1] << 8) | ((uint32_t)e[2] << 16) | ((uint32_t)e[3] << 24);
+      }
+    }
     const uint32_t r0 = ~init;
     const bool live = valid && len >= 4;  // shorter messages take the byte path at the end
     const uint32_t elen = live ? len : 0u;
@@ -165,7 +185,7 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p) {
       uint4 w = make_uint4(0u, 0u, 0u, 0u);
       if (live) {
         if (m >= 0) {
-          w = load16(ptr + m);
+          w = load16<NT>(ptr + m);
           if (m < 4) w.x ^= r0 >> (8 * m);
         } else if (m > -16) {
           w = load_straddle(ptr, m, r0);
@@ -180,10 +200,10 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p) {
       const uint8_t* q = ptr + m;
       uint32_t left = Rmax - it;
       while (left >= 4) {
-        const uint4 a = load16(q);
-        const uint4 b = load16(q + D);
-        const uint4 c = load16(q + 2 * D);
-        const uint4 d = load16(q + 3 * D);
+        const uint4 a = load16<NT>(q);
+        const uint4 b = load16<NT>(q + D);
+        const uint4 c = load16<NT>(q + 2 * D);
+        const uint4 d = load16<NT>(q + 3 * D);
         q += 4 * D;
         TCRC_ROW(a);
         TCRC_ROW(b);
@@ -192,7 +212,7 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p) {
         left -= 4;
       }
       while (left) {
-        const uint4 a = load16(q);
+        const uint4 a = load16<NT>(q);
         q += D;
         TCRC_ROW(a);
         --left;
@@ -228,13 +248,6 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p) {
       const uint32_t masked = ((crc >> 15) | (crc << 17)) + kMaskDelta;
       if (p.out) p.out[buf] = (p.flags & TCRC_F_MASK) ? masked : crc;
       if (p.verify) {
-        uint32_t stored;
-        if (p.expected) {
-          stored = p.expected[buf];
-        } else {
-          const uint8_t* e = (p.flags & TCRC_F_EXPECT_AFTER) ? ptr + len : ptr - 6;
-          stored = (uint32_t)e[0] | ((uint32_t)e[1] << 8) | ((uint32_t)e[2] << 16) | ((uint32_t)e[3] << 24);
-        }
         const bool good = stored == masked;
         if (p.ok) p.ok[buf] = good ? 1 : 0;
         if (!good) {
@@ -245,6 +258,29 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p) {
     }
   }
   if (p.verify && blockIdx.x == 0 && tid == 0) atomicAdd(&p.counts[TCRC_CNT_CHECKED], (unsigned long long)p.n);
+}
+
+// Streaming-read probe: what a kernel that only loads (16 B per lane, whole lines, XOR-folded)
+// reaches on this device; the ceiling the CRC kernels are compared with.
+template <bool NT>
+__global__ __launch_bounds__(kThreads) void k_probe_read(const uint8_t* __restrict__ base, uint64_t n16, uint32_t* out) {
+  const uint64_t nthreads = (uint64_t)gridDim.x * kThreads;
+  uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
+  uint4 acc = make_uint4(0u, 0u, 0u, 0u);
+#define SRC(I_) load16<NT>(base + 16 * (I_))
+  for (; i + 3 * nthreads < n16; i += 4 * nthreads) {
+    const uint4 a = SRC(i), b = SRC(i + nthreads), c = SRC(i + 2 * nthreads), d = SRC(i + 3 * nthreads);
+    acc.x ^= a.x ^ b.x ^ c.x ^ d.x;
+    acc.y ^= a.y ^ b.y ^ c.y ^ d.y;
+    acc.z ^= a.z ^ b.z ^ c.z ^ d.z;
+    acc.w ^= a.w ^ b.w ^ c.w ^ d.w;
+  }
+  for (; i < n16; i += nthreads) {
+    const uint4 a = SRC(i);
+    acc.x ^= a.x; acc.y ^= a.y; acc.z ^= a.z; acc.w ^= a.w;
+  }
+#undef SRC
+  out[(uint64_t)blockIdx.x * kThreads + threadIdx.x] = acc.x ^ acc.y ^ acc.z ^ acc.w;
 }
 
 __global__ void k_counts_reset(unsigned long long* c) {
@@ -276,6 +312,7 @@ struct tcrc_ctx {
   int device = -1;
   int cus = 0;
   int forced_g = 0;
+  bool nontemporal = true;  // batch data is read once: keep it from displacing other lines in L2/MALL
   uint32_t* d_tab_main[kGeoCount] = {nullptr, nullptr, nullptr};
   uint32_t* d_tab_aux[kGeoCount] = {nullptr, nullptr, nullptr};
   std::string description;
@@ -298,7 +335,10 @@ int launch_batch(tcrc_ctx* ctx, BatchParams p, hipStream_t s) {
   uint64_t wgs = (rounds + kWavesPerWg - 1) / kWavesPerWg;
   if (wgs > (uint64_t)ctx->cus) wgs = (uint64_t)ctx->cus;
   if (wgs == 0) wgs = 1;
-  hipLaunchKernelGGL(k_crc_batch<G>, dim3((unsigned)wgs), dim3(kThreads), 0, s, p);
+  if (ctx->nontemporal)
+    hipLaunchKernelGGL((k_crc_batch<G, true>), dim3((unsigned)wgs), dim3(kThreads), 0, s, p);
+  else
+    hipLaunchKernelGGL((k_crc_batch<G, false>), dim3((unsigned)wgs), dim3(kThreads), 0, s, p);
   HIP_TRY(hipGetLastError());
   return TCRC_OK;
 }
@@ -346,6 +386,7 @@ int tcrc_init(int device, tcrc_ctx** out) {
   ctx->device = device;
   ctx->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (const char* e = getenv("TCRC_LANES_PER_BUFFER")) ctx->forced_g = atoi(e);
+  if (const char* e = getenv("TCRC_NONTEMPORAL")) ctx->nontemporal = atoi(e) != 0;
   for (int gi = 0; gi < kGeoCount; ++gi) {
     const int G = kGeoLanes[gi];
     int log2g = 0;
@@ -395,6 +436,22 @@ int tcrc_dev_counts_reset(tcrc_ctx* ctx, uint64_t* d_counts, void* stream) {
   if (!ctx || !d_counts) return fail(TCRC_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(ctx->device));
   hipLaunchKernelGGL(k_counts_reset, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)d_counts);
+  HIP_TRY(hipGetLastError());
+  return TCRC_OK;
+}
+
+int tcrc_dev_probe_read(tcrc_ctx* ctx, const void* d_base, uint64_t nbytes, uint32_t* d_scratch, uint32_t wgs_per_cu,
+                        void* stream) {
+  if (!ctx || !d_base || !d_scratch) return fail(TCRC_ERR_INVALID, "null argument");
+  if (((uintptr_t)d_base & 15u) != 0) return fail(TCRC_ERR_INVALID, "probe needs a 16-byte aligned base");
+  if (wgs_per_cu == 0 || wgs_per_cu > 2) return fail(TCRC_ERR_INVALID, "wgs_per_cu must be 1 or 2");
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (ctx->nontemporal)
+    hipLaunchKernelGGL(k_probe_read<true>, dim3((unsigned)ctx->cus * wgs_per_cu), dim3(kThreads), 0,
+                       (hipStream_t)stream, (const uint8_t*)d_base, nbytes / 16, d_scratch);
+  else
+    hipLaunchKernelGGL(k_probe_read<false>, dim3((unsigned)ctx->cus * wgs_per_cu), dim3(kThreads), 0,
+                       (hipStream_t)stream, (const uint8_t*)d_base, nbytes / 16, d_scratch);
   HIP_TRY(hipGetLastError());
   return TCRC_OK;
 }
