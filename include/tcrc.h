@@ -95,6 +95,35 @@ int tcrc_dev_batch_verify(tcrc_ctx* ctx, const void* d_base, const tcrc_desc* d_
                           const uint8_t* d_suffix, uint32_t flags, const uint32_t* d_expected, uint32_t* d_out,
                           uint8_t* d_ok, uint64_t* d_counts, void* stream);
 
+/* ---- write-ahead-log images ------------------------------------------------------ */
+/* How the structural walk of one 32 KiB log block ended (db/log_reader.cc:314-384). */
+#define TCRC_WAL_END_CLEAN 0          /* records fill the block exactly */
+#define TCRC_WAL_END_TRAILER 1        /* fewer than a header's worth of bytes left: block trailer */
+#define TCRC_WAL_END_SHORT_AT_EOF 2   /* same, but the file ends here: truncated header (kBadHeader) */
+#define TCRC_WAL_END_BAD_LEN 3        /* header_size + length runs past the block (kBadRecordLen) */
+#define TCRC_WAL_END_BAD_LEN_AT_EOF 4 /* same in the file's last block (kBadHeader / kEof) */
+#define TCRC_WAL_END_ZERO_RECORD 5    /* type 0 and length 0: preallocated space (kBadRecord) */
+#define TCRC_WAL_END_OLD_RECORD 6     /* recyclable header with another log number (kOldRecord) */
+
+/* Result for one 32 KiB block of a log image. */
+typedef struct tcrc_wal_block {
+  uint32_t n_records;  /* records that pass every structural check of ReadPhysicalRecord */
+  uint32_t first_bad;  /* smallest index of a record whose CRC does not match, 0xffffffff if none */
+  uint32_t end_offset; /* offset inside the block where the walk stopped */
+  uint32_t end_code;   /* TCRC_WAL_END_* */
+} tcrc_wal_block;
+
+/* Verifies every physical record of a complete log image resident on the GPU the way
+ * log::Reader::ReadPhysicalRecord does with checksum=true (db/log_reader.cc:314-406):
+ * d_blocks[b] describes block b = bytes [32768*b, 32768*(b+1)) of the image.  Within a
+ * block the reference stops at the first bad checksum, so first_bad is what its policy
+ * layer needs.  d_counts accumulates TCRC_CNT_* over all candidate records.  Synchronises
+ * the stream once per GiB (the record count is needed on the host); on return the rest
+ * of the work is enqueued on `stream`.  *h_records, if not NULL, receives the number of
+ * candidate records. */
+int tcrc_dev_wal_verify(tcrc_ctx* ctx, const void* d_img, uint64_t size, uint64_t log_number, tcrc_wal_block* d_blocks,
+                        uint64_t* d_counts, uint64_t* h_records, void* stream);
+
 /* Sets d_counts to {0, ~0, 0}. */
 int tcrc_dev_counts_reset(tcrc_ctx* ctx, uint64_t* d_counts, void* stream);
 

@@ -593,3 +593,48 @@ uint32_t oracle_random_uniform(oracle_random* r, int n) { return oracle_random_n
 uint32_t oracle_random_skewed(oracle_random* r, int max_log) {
   return oracle_random_uniform(r, 1 << oracle_random_uniform(r, max_log + 1));
 }
+
+/* Per-block view of ReadPhysicalRecord over a complete image (checksum on, no retry):
+ * for block b, out[4b..] = {n_records, first_bad, end_offset, end_code} where n_records
+ * counts the records that pass the structural checks of db/log_reader.cc:317-384 when
+ * every checksum is taken as good, first_bad is the index of the first of them whose
+ * checksum (db/log_reader.cc:388-390) fails (0xffffffff if none), end_offset is where
+ * that walk stops inside the block and end_code says why:
+ * 0 block exactly full, 1 trailer shorter than a header, 2 the same at end of file,
+ * 3 length runs past the block, 4 the same in the last block, 5 zero type and length,
+ * 6 recyclable record of another log number. */
+void oracle_wal_scan_blocks(const uint8_t* img, size_t n, uint64_t log_number, uint32_t* out) {
+  size_t b = 0;
+  for (size_t blk = 0; blk < n; blk += kBlockSize, b++) {
+    size_t end = blk + kBlockSize < n ? blk + kBlockSize : n;
+    int last = end == n;
+    size_t p = blk;
+    uint32_t count = 0, first_bad = 0xffffffffu, code = 0;
+    for (;;) {
+      size_t remaining = end - p;
+      if (remaining < (size_t)kHeaderSize) {
+        code = remaining == 0 ? 0 : (last ? 2 : 1);
+        break;
+      }
+      const uint8_t* h = img + p;
+      unsigned type = (unsigned)(int)(signed char)h[6];
+      uint32_t len = h[4] | ((uint32_t)h[5] << 8);
+      size_t hs = kHeaderSize;
+      if (type >= kRecyclableFullType && type <= kRecyclableLastType) {
+        hs = kRecyclableHeaderSize;
+        if (remaining < hs) { code = last ? 2 : 1; break; }
+        if ((uint64_t)get_le32(h + 7) != log_number) { code = 6; break; }
+      }
+      if (hs + len > remaining) { code = last ? 4 : 3; break; }
+      if (type == kZeroType && len == 0) { code = 5; break; }
+      uint32_t actual = oracle_crc32c_extend(0, h + 6, len + hs - 6);
+      if (actual != oracle_crc32c_unmask(get_le32(h)) && first_bad == 0xffffffffu) first_bad = count;
+      count++;
+      p += hs + len;
+    }
+    out[4 * b + 0] = count;
+    out[4 * b + 1] = first_bad;
+    out[4 * b + 2] = (uint32_t)(p - blk);
+    out[4 * b + 3] = code;
+  }
+}

@@ -18,6 +18,11 @@ F_MASK, F_EXPECT_AFTER, F_EXPECT_BEFORE = 1, 2, 4
 CNT_MISMATCH, CNT_FIRST_BAD, CNT_CHECKED, CNT_WORDS = 0, 1, 2, 3
 
 
+class WalBlock(C.Structure):
+    _fields_ = [("n_records", C.c_uint32), ("first_bad", C.c_uint32), ("end_offset", C.c_uint32),
+                ("end_code", C.c_uint32)]
+
+
 class Desc(C.Structure):
     _fields_ = [("offset", C.c_uint64), ("len", C.c_uint32), ("init", C.c_uint32)]
 
@@ -31,6 +36,7 @@ SIGNATURES = {
     "tcrc_mask": (_u32, [_u32]),
     "tcrc_unmask": (_u32, [_u32]),
     "tcrc_dev_counts_reset": (_i, [_vp, _vp, _vp]),
+    "tcrc_dev_wal_verify": (_i, [_vp, _vp, _u64, _u64, _vp, _vp, C.POINTER(_u64), _vp]),
     "tcrc_dev_probe_read": (_i, [_vp, _vp, _u64, _vp, _u32, _vp]),
     "tcrc_dev_blocks_stamp": (_i, [_vp, _vp, _u64, _u32, _u64, _u32, _i, _vp, _u32, _vp, _vp]),
     "tcrc_dev_blocks_verify": (_i, [_vp, _vp, _u64, _u32, _u64, _u32, _i, _vp, _u32, _vp, _vp, _vp, _vp, _vp]),
@@ -102,6 +108,13 @@ class Engine:
 
     def probe_read(self, base, nbytes, scratch, wgs_per_cu=1, stream=None):
         check(lib.tcrc_dev_probe_read(self.ctx, _dp(base), nbytes, _dp(scratch), wgs_per_cu, self._stream(stream)))
+
+    def wal_verify(self, img, size, log_number, blocks, counts, stream=None):
+        """blocks: int32/uint32 device tensor of shape [ceil(size/32768), 4]; returns the record count."""
+        n = C.c_uint64(0)
+        check(lib.tcrc_dev_wal_verify(self.ctx, _dp(img), size, log_number, _dp(blocks), _dp(counts), C.byref(n),
+                                      self._stream(stream)))
+        return n.value
 
     def counts_reset(self, counts, stream=None):
         check(lib.tcrc_dev_counts_reset(self.ctx, _dp(counts), self._stream(stream)))

@@ -28,8 +28,10 @@
 
 #include <string>
 
-#include "../../include/tcrc.h"
+#include "tcrc_internal.h"
 #include "gf2.h"
+
+using namespace tcrc_internal;
 
 namespace {
 
@@ -43,24 +45,6 @@ template <> struct Geo<8>  { static constexpr int kLog2 = 3; };
 template <> struct Geo<16> { static constexpr int kLog2 = 4; };
 template <> struct Geo<64> { static constexpr int kLog2 = 6; };
 
-struct BatchParams {
-  const uint8_t* base;
-  const tcrc_desc* desc;  // NULL: uniform geometry below
-  uint64_t n;
-  uint64_t stride;
-  uint32_t block_len;
-  uint32_t uniform_init;
-  const uint8_t* suffix;   // per-buffer suffix byte, or NULL
-  int32_t uniform_suffix;  // >= 0: same suffix byte for all buffers
-  uint32_t flags;
-  uint32_t verify;         // 1: compare with expected
-  uint32_t* out;
-  const uint32_t* expected;
-  uint8_t* ok;
-  unsigned long long* counts;
-  const uint32_t* tab_main;  // 1024 dwords: Z_D set
-  const uint32_t* tab_aux;   // (1+log2 G) sets of 1024 dwords: Z_4, Z_16, Z_32, ...
-};
 
 typedef unsigned int v4u __attribute__((ext_vector_type(4)));
 typedef v4u v4u_any __attribute__((aligned(1)));
@@ -125,19 +109,29 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p) {
   const uint32_t* aux = lds + kMainDwords;
   const uint64_t wave = (uint64_t)blockIdx.x * kWavesPerWg + (tid >> 6);
   const uint64_t nwaves = (uint64_t)gridDim.x * kWavesPerWg;
-  const uint64_t nrounds = (p.n + GPW - 1) / GPW;
+  uint64_t n = p.n;
+  if (p.n_dev) {
+    const uint64_t nd = *p.n_dev;
+    n = nd < n ? nd : n;
+  }
+  const uint64_t nrounds = (n + GPW - 1) / GPW;
+  const bool wal_items = (p.flags & kFlagWalItems) != 0;
 
   for (uint64_t round = wave; round < nrounds; round += nwaves) {
     const uint64_t buf = round * GPW + grp;
-    const bool valid = buf < p.n;
+    const bool valid = buf < n;
     uint64_t off = 0;
-    uint32_t len = 0, init = 0;
+    uint32_t len = 0, init = 0, item_index = 0;
     if (valid) {
       if (p.desc) {
         const tcrc_desc d = p.desc[buf];
         off = d.offset;
         len = d.len;
         init = d.init;
+        if (wal_items) {
+          item_index = init;  // record index inside its 32 KiB block
+          init = 0;
+        }
       } else {
         off = buf * p.stride;
         len = p.block_len;
@@ -253,11 +247,12 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p) {
         if (!good) {
           atomicAdd(&p.counts[TCRC_CNT_MISMATCH], 1ull);
           atomicMin(&p.counts[TCRC_CNT_FIRST_BAD], (unsigned long long)buf);
+          if (wal_items) atomicMin(&p.wal_blocks[p.item_block[buf]].first_bad, item_index);
         }
       }
     }
   }
-  if (p.verify && blockIdx.x == 0 && tid == 0) atomicAdd(&p.counts[TCRC_CNT_CHECKED], (unsigned long long)p.n);
+  if (p.verify && blockIdx.x == 0 && tid == 0) atomicAdd(&p.counts[TCRC_CNT_CHECKED], (unsigned long long)n);
 }
 
 // Streaming-read probe: what a kernel that only loads (16 B per lane, whole lines, XOR-folded)
@@ -289,36 +284,8 @@ __global__ void k_counts_reset(unsigned long long* c) {
   c[TCRC_CNT_CHECKED] = 0ull;
 }
 
-thread_local std::string g_err;
-
-int fail(int code, const std::string& msg) {
-  g_err = msg;
-  return code;
-}
-
-#define HIP_TRY(expr)                                                                         \
-  do {                                                                                        \
-    hipError_t e_ = (expr);                                                                   \
-    if (e_ != hipSuccess)                                                                     \
-      return fail(TCRC_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));           \
-  } while (0)
-
-constexpr int kGeoCount = 3;
 constexpr int kGeoLanes[kGeoCount] = {8, 16, 64};
 
-}  // namespace
-
-struct tcrc_ctx {
-  int device = -1;
-  int cus = 0;
-  int forced_g = 0;
-  bool nontemporal = true;  // batch data is read once: keep it from displacing other lines in L2/MALL
-  uint32_t* d_tab_main[kGeoCount] = {nullptr, nullptr, nullptr};
-  uint32_t* d_tab_aux[kGeoCount] = {nullptr, nullptr, nullptr};
-  std::string description;
-};
-
-namespace {
 
 int geo_index(int g) {
   for (int i = 0; i < kGeoCount; ++i)
@@ -343,7 +310,39 @@ int launch_batch(tcrc_ctx* ctx, BatchParams p, hipStream_t s) {
   return TCRC_OK;
 }
 
-int run_batch(tcrc_ctx* ctx, BatchParams p, uint32_t typical_len, void* stream) {
+}  // namespace
+
+namespace tcrc_internal {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+int scratch_reserve(tcrc_ctx* ctx, tcrc_scratch* s, size_t bytes) {
+  if (s->bytes >= bytes) return TCRC_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (s->p) {
+    HIP_TRY(hipDeviceSynchronize());  // earlier work may still use the old block
+    (void)hipFree(s->p);
+    s->p = nullptr;
+    s->bytes = 0;
+  }
+  size_t want = bytes + bytes / 4 + 4096;
+  HIP_TRY(hipMalloc(&s->p, want));
+  s->bytes = want;
+  return TCRC_OK;
+}
+
+void scratch_release(tcrc_scratch* s) {
+  if (s->p) (void)hipFree(s->p);
+  s->p = nullptr;
+  s->bytes = 0;
+}
+
+int run_batch(tcrc_ctx* ctx, BatchParams p, void* stream) {
   if (!ctx) return fail(TCRC_ERR_INVALID, "null context");
   if (p.n == 0) return TCRC_OK;
   if (!p.base) return fail(TCRC_ERR_INVALID, "null base pointer");
@@ -351,7 +350,6 @@ int run_batch(tcrc_ctx* ctx, BatchParams p, uint32_t typical_len, void* stream) 
   hipStream_t s = (hipStream_t)stream;
   int g = ctx->forced_g;
   if (g == 0) g = 8;
-  (void)typical_len;
   switch (g) {
     case 8: return launch_batch<8>(ctx, p, s);
     case 16: return launch_batch<16>(ctx, p, s);
@@ -360,11 +358,11 @@ int run_batch(tcrc_ctx* ctx, BatchParams p, uint32_t typical_len, void* stream) 
   }
 }
 
-}  // namespace
+}  // namespace tcrc_internal
 
 extern "C" {
 
-const char* tcrc_last_error(void) { return g_err.c_str(); }
+const char* tcrc_last_error(void) { return tcrc_internal::g_err.c_str(); }
 
 uint32_t tcrc_mask(uint32_t crc) { return ((crc >> 15) | (crc << 17)) + kMaskDelta; }
 uint32_t tcrc_unmask(uint32_t masked) {
@@ -426,6 +424,8 @@ int tcrc_shutdown(tcrc_ctx* ctx) {
     if (ctx->d_tab_main[gi]) (void)hipFree(ctx->d_tab_main[gi]);
     if (ctx->d_tab_aux[gi]) (void)hipFree(ctx->d_tab_aux[gi]);
   }
+  for (tcrc_scratch* s : {&ctx->wal_counts, &ctx->wal_first, &ctx->wal_items, &ctx->wal_item_block, &ctx->wal_misc})
+    scratch_release(s);
   delete ctx;
   return TCRC_OK;
 }
@@ -477,7 +477,7 @@ int tcrc_dev_blocks_stamp(tcrc_ctx* ctx, const void* d_base, uint64_t n_blocks, 
   p.uniform_suffix = suffix_byte >= 0 ? (suffix_byte & 0xff) : -1;
   p.flags = flags;
   p.out = d_out;
-  return run_batch(ctx, p, block_len, stream);
+  return run_batch(ctx, p, stream);
 }
 
 int tcrc_dev_blocks_verify(tcrc_ctx* ctx, const void* d_base, uint64_t n_blocks, uint32_t block_len, uint64_t stride,
@@ -502,7 +502,7 @@ int tcrc_dev_blocks_verify(tcrc_ctx* ctx, const void* d_base, uint64_t n_blocks,
   p.expected = d_expected;
   p.ok = d_ok;
   p.counts = (unsigned long long*)d_counts;
-  return run_batch(ctx, p, block_len, stream);
+  return run_batch(ctx, p, stream);
 }
 
 int tcrc_dev_batch_stamp(tcrc_ctx* ctx, const void* d_base, const tcrc_desc* d_desc, uint64_t n,
@@ -516,7 +516,7 @@ int tcrc_dev_batch_stamp(tcrc_ctx* ctx, const void* d_base, const tcrc_desc* d_d
   p.uniform_suffix = -1;
   p.flags = flags;
   p.out = d_out;
-  return run_batch(ctx, p, 0, stream);
+  return run_batch(ctx, p, stream);
 }
 
 int tcrc_dev_batch_verify(tcrc_ctx* ctx, const void* d_base, const tcrc_desc* d_desc, uint64_t n,
@@ -538,7 +538,7 @@ int tcrc_dev_batch_verify(tcrc_ctx* ctx, const void* d_base, const tcrc_desc* d_
   p.expected = d_expected;
   p.ok = d_ok;
   p.counts = (unsigned long long*)d_counts;
-  return run_batch(ctx, p, 0, stream);
+  return run_batch(ctx, p, stream);
 }
 
 }  // extern "C"

@@ -1,0 +1,75 @@
+// Declarations shared by the translation units of libtcrc.so (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "../../include/tcrc.h"
+
+namespace tcrc_internal {
+
+// internal flag bits (above the public TCRC_F_* ones)
+constexpr uint32_t kFlagWalItems = 0x100u;  // descriptors are log records: desc.init = index inside the 32 KiB block
+
+struct BatchParams {
+  const uint8_t* base;
+  const tcrc_desc* desc;  // NULL: uniform geometry below
+  uint64_t n;
+  uint64_t stride;
+  uint32_t block_len;
+  uint32_t uniform_init;
+  const uint8_t* suffix;   // per-buffer suffix byte, or NULL
+  int32_t uniform_suffix;  // >= 0: same suffix byte for all buffers
+  uint32_t flags;
+  uint32_t verify;         // 1: compare with expected
+  uint32_t* out;
+  const uint32_t* expected;
+  uint8_t* ok;
+  unsigned long long* counts;
+  const unsigned long long* n_dev;  // when set, the batch size is read from device memory (<= n)
+  const uint32_t* item_block;       // kFlagWalItems: 32 KiB block index of every item
+  tcrc_wal_block* wal_blocks;       // kFlagWalItems: per block result (first_bad is lowered on a mismatch)
+  const uint32_t* tab_main;  // 1024 dwords: Z_D set
+  const uint32_t* tab_aux;   // (1+log2 G) sets of 1024 dwords: Z_4, Z_16, Z_32, ...
+};
+
+constexpr int kGeoCount = 3;
+
+int fail(int code, const std::string& msg);
+
+// Launches the batch CRC kernel for the geometry the context prefers.
+int run_batch(tcrc_ctx* ctx, BatchParams p, void* stream);
+
+#define HIP_TRY(expr)                                                                                  \
+  do {                                                                                                 \
+    hipError_t e_ = (expr);                                                                            \
+    if (e_ != hipSuccess)                                                                              \
+      return tcrc_internal::fail(TCRC_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));     \
+  } while (0)
+
+}  // namespace tcrc_internal
+
+// Grow-only device scratch owned by a context.
+struct tcrc_scratch {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+struct tcrc_ctx {
+  int device = -1;
+  int cus = 0;
+  int forced_g = 0;
+  bool nontemporal = true;  // batch data is read once: keep it from displacing other lines in L2/MALL
+  uint32_t* d_tab_main[tcrc_internal::kGeoCount] = {nullptr, nullptr, nullptr};
+  uint32_t* d_tab_aux[tcrc_internal::kGeoCount] = {nullptr, nullptr, nullptr};
+  std::string description;
+  // log-scan scratch (tcrc_wal.hip)
+  tcrc_scratch wal_counts, wal_first, wal_items, wal_item_block, wal_misc;
+};
+
+namespace tcrc_internal {
+// Makes sure s holds at least `bytes` of device memory on the context's GPU.
+int scratch_reserve(tcrc_ctx* ctx, tcrc_scratch* s, size_t bytes);
+void scratch_release(tcrc_scratch* s);
+}  // namespace tcrc_internal

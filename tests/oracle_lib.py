@@ -61,6 +61,7 @@ def lib():
             "oracle_wal_reader_unmark_eof": (None, [vp]),
             "oracle_wal_reader_read_record": (i, [vp, i, C.POINTER(vp), C.POINTER(sz)]),
             "oracle_wal_list_physical": (sz, [vp, sz, u64, vp, sz]),
+            "oracle_wal_scan_blocks": (None, [vp, sz, u64, vp]),
         }
         for name, (res, args) in sig.items():
             f = getattr(L, name)
@@ -270,3 +271,40 @@ def list_physical(img, log_number):
     out = np.zeros(cap * 4, dtype=np.uint64)
     n = lib().oracle_wal_list_physical(_ptr(arr), arr.size, log_number, _ptr(out), cap)
     return out[: 4 * min(n, cap)].reshape(-1, 4), n
+
+
+def wal_scan_blocks(img, log_number):
+    """Per 32 KiB block: (n_records, first_bad, end_offset, end_code); see oracle/wal_oracle.c."""
+    arr = np.frombuffer(img, dtype=np.uint8) if not isinstance(img, np.ndarray) else img
+    nb = (arr.size + 32767) // 32768
+    out = np.zeros((nb, 4), dtype=np.uint32)
+    if nb:
+        lib().oracle_wal_scan_blocks(_ptr(arr), arr.size, log_number, _ptr(out))
+    return out
+
+
+def build_wal_image(recycle, log_number=123, n_random=500, seed=301, edge=True):
+    """A log image like db/log_test.cc's RandomRead (Random(seed).Skewed(17) sizes) plus
+    records placed to produce every trailer length 0..10 and the fragment edge sizes."""
+    t = OracleLog(recycle=recycle, log_number=log_number)
+    rnd = Random(seed)
+    hs = 11 if recycle else 7
+    if edge:
+        for sz in (0, 1, 32768 - hs, 32768 - hs + 1, 65536, 100000, 32761, 32762):
+            t.write(big_string(b"e%d." % sz, sz))
+        for trailer in range(0, 11):
+            # pad the current block so that exactly `trailer` bytes stay free after a record
+            used = t.written_bytes() % 32768
+            room = 32768 - used
+            body = room - hs - trailer
+            if body < 0:
+                t.write(big_string(b"p", room + 100))
+                used = t.written_bytes() % 32768
+                body = 32768 - used - hs - trailer
+            t.write(big_string(b"t%d." % trailer, body))
+            t.write(b"after-trailer")
+    for i in range(n_random):
+        t.write(big_string(number_string(i), rnd.skewed(17)))
+    img = t.contents()
+    t.close()
+    return img

@@ -1,0 +1,102 @@
+"""GPU parity for write-ahead-log images: the device scan against the CPU oracle's reader rules."""
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import gpu_util as G
+    e = G.engine()
+    yield e
+    e.close()
+
+
+def device_scan(eng, img, log_number):
+    import gpu_util as G
+    import terarkdb_amd.capi as capi
+    arr = np.frombuffer(img, dtype=np.uint8).copy() if not isinstance(img, np.ndarray) else img
+    dev = G.to_dev(arr)
+    nb = (arr.size + 32767) // 32768
+    blocks = torch.zeros((nb, 4), dtype=torch.int32, device="cuda")
+    counts = torch.zeros(capi.CNT_WORDS, dtype=torch.int64, device="cuda")
+    eng.counts_reset(counts)
+    nrec = eng.wal_verify(dev, arr.size, log_number, blocks, counts)
+    torch.cuda.synchronize()
+    return blocks.cpu().numpy().view(np.uint32), counts.cpu().numpy().view(np.uint64), nrec
+
+
+@pytest.mark.parametrize("recycle", [0, 1])
+def test_clean_image_all_records_verify(eng, recycle):
+    import terarkdb_amd.capi as capi
+    img = O.build_wal_image(recycle)
+    want = O.wal_scan_blocks(img, 123)
+    got, counts, nrec = device_scan(eng, img, 123)
+    assert (got == want).all()
+    assert int(counts[capi.CNT_MISMATCH]) == 0
+    assert nrec == int(want[:, 0].sum()) == int(counts[capi.CNT_CHECKED])
+    recs, n = O.list_physical(img, 123)
+    assert n == nrec
+
+
+@pytest.mark.parametrize("recycle", [0, 1])
+def test_bit_flips_give_the_cpu_readers_verdicts(eng, recycle):
+    """Seeded single-bit flips in payload, type byte, crc bytes and length bytes."""
+    img = bytearray(O.build_wal_image(recycle, n_random=300))
+    recs, n = O.list_physical(bytes(img), 123)
+    rng = np.random.default_rng(5 + recycle)
+    hs = 11 if recycle else 7
+    chosen = rng.choice(n, size=60, replace=False)
+    for k, ri in enumerate(chosen):
+        off, typ, ln, _ = (int(x) for x in recs[ri])
+        kind = k % 5
+        if kind == 0 and ln > 0:
+            pos = off + hs + int(rng.integers(0, ln))      # payload
+        elif kind == 1:
+            pos = off + 6                                  # type byte
+        elif kind == 2:
+            pos = off + int(rng.integers(0, 4))            # stored crc
+        elif kind == 3:
+            pos = off + 4 + int(rng.integers(0, 2))        # length bytes
+        else:
+            pos = off + (7 if recycle else 6)              # log number / type
+        img[pos] ^= 1 << int(rng.integers(0, 8))
+    img = bytes(img)
+    want = O.wal_scan_blocks(img, 123)
+    got, counts, nrec = device_scan(eng, img, 123)
+    bad = np.nonzero((got != want).any(axis=1))[0]
+    assert bad.size == 0, (bad[:5], got[bad[:5]], want[bad[:5]])
+    assert (want[:, 1] != 0xffffffff).sum() > 10  # the flips really produced checksum failures
+
+
+def test_wrong_log_number_and_truncations(eng):
+    img = O.build_wal_image(1, n_random=50)
+    # another log number: every recyclable record is an "old record"
+    want = O.wal_scan_blocks(img, 124)
+    got, counts, nrec = device_scan(eng, img, 124)
+    assert (got == want).all() and nrec == 0
+    for cut in (1, 3, 6, 7, 8, 11, 12, 500, 32768, 32769, 40000):
+        part = img[: len(img) - cut]
+        want = O.wal_scan_blocks(part, 123)
+        got, counts, nrec = device_scan(eng, part, 123)
+        assert (got == want).all(), cut
+    # preallocated (zeroed) tail, as produced by fallocate-style writers
+    padded = img + bytes(70000)
+    want = O.wal_scan_blocks(padded, 123)
+    got, counts, nrec = device_scan(eng, padded, 123)
+    assert (got == want).all()
+
+
+def test_many_tiny_records(eng):
+    t = O.OracleLog(recycle=False, log_number=9)
+    for i in range(30000):
+        t.write(b"" if i % 3 == 0 else O.number_string(i))
+    img = t.contents()
+    t.close()
+    want = O.wal_scan_blocks(img, 9)
+    got, counts, nrec = device_scan(eng, img, 9)
+    assert (got == want).all() and nrec == int(want[:, 0].sum()) and nrec >= 30000
