@@ -127,6 +127,25 @@ int tcrc_dev_wal_verify(tcrc_ctx* ctx, const void* d_img, uint64_t size, uint64_
 /* Sets d_counts to {0, ~0, 0}. */
 int tcrc_dev_counts_reset(tcrc_ctx* ctx, uint64_t* d_counts, void* stream);
 
+/* ---- host-memory batches --------------------------------------------------------- */
+/* The reference's path starts and ends in host memory (log file buffers, blocks read through
+ * env/io_posix.cc).  These entry points take host pointers, copy the bytes to the GPU, run the
+ * device path above and copy the results back; they return when the results are in place.
+ * One such call runs at a time per context (they share the context's staging memory). */
+void* tcrc_host_alloc(tcrc_ctx* ctx, size_t bytes); /* pinned memory: copies from it run at link rate */
+void tcrc_host_free(tcrc_ctx* ctx, void* p);
+int tcrc_host_batch_stamp(tcrc_ctx* ctx, const void* h_base, uint64_t base_bytes, const tcrc_desc* h_desc, uint64_t n,
+                          const uint8_t* h_suffix, uint32_t flags, uint32_t* h_out);
+int tcrc_host_blocks_stamp(tcrc_ctx* ctx, const void* h_base, uint64_t n_blocks, uint32_t block_len, uint64_t stride,
+                           uint32_t init, int suffix_byte, uint32_t flags, uint32_t* h_out);
+/* h_counts: 3 x uint64 (TCRC_CNT_*), filled by the call. */
+int tcrc_host_batch_verify(tcrc_ctx* ctx, const void* h_base, uint64_t base_bytes, const tcrc_desc* h_desc, uint64_t n,
+                           const uint8_t* h_suffix, uint32_t flags, const uint32_t* h_expected, uint32_t* h_out,
+                           uint8_t* h_ok, uint64_t* h_counts);
+/* Host form of tcrc_dev_wal_verify: h_blocks gets ceil(size/32768) entries. */
+int tcrc_host_wal_verify(tcrc_ctx* ctx, const void* h_img, uint64_t size, uint64_t log_number, tcrc_wal_block* h_blocks,
+                         uint64_t* h_counts, uint64_t* h_records);
+
 /* ---- measurement aid ----------------------------------------------------------- */
 /* Streams nbytes from d_base with loads only (no checksum work) so a benchmark can report
  * the read rate this device actually reaches beside the CRC kernels' rate.  d_scratch

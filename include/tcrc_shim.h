@@ -1,0 +1,85 @@
+/*
+ * C entry points over libtcrc.so's C++ classes that keep the reference's call surface:
+ *   terarkdb_amd::log::Writer   ~ log::Writer  (db/log_writer.h:67-113)
+ *   terarkdb_amd::log::Reader   ~ log::Reader  (db/log_reader.h:35-150)
+ *   terarkdb_amd::WriteRawBlocks / CheckBlockChecksums ~ the checksum parts of
+ *       BlockBasedTableBuilder::WriteRawBlock (table/block_based_table_builder.cc:580-646) and
+ *       BlockFetcher::CheckBlockChecksum (table/block_fetcher.cc:36-71)
+ * C++ callers include the headers under terarkdb_amd/host/ directly; these wrappers exist for
+ * bindings (ctypes, cgo, JNI) and are what the test-suite drives.  Files are either POSIX
+ * paths or in-memory files (the fakes of db/log_test.cc:49-114 and util/testutil.h:201-252).
+ */
+#ifndef TCRC_SHIM_H_
+#define TCRC_SHIM_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "tcrc.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Checksum seams as callbacks (used to exercise the host logic without a GPU): return 0 on success. */
+typedef int (*tcrc_shim_stamp_fn)(void* user, const char* base, size_t base_bytes, const tcrc_desc* spans, size_t n,
+                                  uint32_t* masked_out);
+typedef int (*tcrc_shim_scan_fn)(void* user, const char* img, size_t n, uint64_t log_number, tcrc_wal_block* blocks);
+
+/* in-memory file */
+void* tcrc_shim_memfile_new(void);
+void tcrc_shim_memfile_free(void* f);
+size_t tcrc_shim_memfile_size(void* f);
+char* tcrc_shim_memfile_data(void* f);
+void tcrc_shim_memfile_drop(void* f, size_t bytes);
+void tcrc_shim_memfile_append(void* f, const void* data, size_t n);
+
+/* log::Writer(dest, log_number, recycle_log_files, manual_flush): AddRecord / WriteBuffer */
+void* tcrc_shim_wal_writer_new(tcrc_ctx* ctx, void* memfile, uint64_t log_number, int recycle, int manual_flush,
+                               int overwrite);
+void* tcrc_shim_wal_writer_new_cb(tcrc_shim_stamp_fn fn, void* user, void* memfile, uint64_t log_number, int recycle,
+                                  int manual_flush, int overwrite);
+void* tcrc_shim_wal_writer_open(tcrc_ctx* ctx, const char* path, uint64_t log_number, int recycle, int manual_flush);
+int tcrc_shim_wal_writer_add_record(void* w, const void* data, size_t n);
+int tcrc_shim_wal_writer_write_buffer(void* w);
+const char* tcrc_shim_wal_writer_status(void* w);
+uint64_t tcrc_shim_wal_writer_physical_records(void* w);
+uint64_t tcrc_shim_wal_writer_crc_bytes(void* w);
+void tcrc_shim_wal_writer_free(void* w);
+
+/* log::Reader(file, reporter, checksum, log_num, retry_after_eof): ReadRecord / UnmarkEOF / ... */
+void* tcrc_shim_wal_reader_new(tcrc_ctx* ctx, void* memfile, int checksum, uint64_t log_number, int retry_after_eof);
+void* tcrc_shim_wal_reader_new_cb(tcrc_shim_scan_fn fn, void* user, void* memfile, int checksum, uint64_t log_number,
+                                  int retry_after_eof);
+void* tcrc_shim_wal_reader_open(tcrc_ctx* ctx, const char* path, int checksum, uint64_t log_number);
+/* Verifies img[0..n) (or, with img == NULL, the in-memory file's present contents) in one
+ * pass and attaches the verdicts, so ReadRecord does not ask block by block. */
+int tcrc_shim_wal_reader_attach_image(void* r, const void* img, size_t n);
+/* mode = WALRecoveryMode value; returns 1 and the record, or 0 at end of input. */
+int tcrc_shim_wal_reader_read_record(void* r, int mode, const char** rec, size_t* n);
+size_t tcrc_shim_wal_reader_dropped_bytes(void* r);
+const char* tcrc_shim_wal_reader_report(void* r);
+int tcrc_shim_wal_reader_is_eof(void* r);
+void tcrc_shim_wal_reader_unmark_eof(void* r);
+uint64_t tcrc_shim_wal_reader_last_record_offset(void* r);
+uint64_t tcrc_shim_wal_reader_verifier_calls(void* r);
+void tcrc_shim_wal_reader_force_error(void* r, size_t position);
+void tcrc_shim_wal_reader_force_eof(void* r, size_t position);
+int tcrc_shim_wal_reader_read_after_partial(void* r);
+void tcrc_shim_wal_reader_free(void* r);
+
+/* SST block trailers.  checksum_type: 0 none, 1 CRC32c, 2/3 xxHash kinds (declined: returns -2). */
+int tcrc_shim_block_trailers(tcrc_ctx* ctx, const void* base, const uint64_t* offsets, const uint64_t* sizes,
+                             const uint8_t* types, size_t n, int checksum_type, uint8_t* trailers_out);
+int tcrc_shim_write_raw_blocks(tcrc_ctx* ctx, void* memfile, const void* base, const uint64_t* offsets,
+                               const uint64_t* sizes, const uint8_t* types, size_t n, int checksum_type,
+                               uint64_t* handle_offsets_out);
+/* returns 0 all good, 1 at least one mismatch (first_message holds the reference's Corruption text), <0 error */
+int tcrc_shim_check_blocks(tcrc_ctx* ctx, const void* image, size_t image_size, uint64_t image_file_offset,
+                           const uint64_t* handle_offsets, const uint64_t* handle_sizes, size_t n, int checksum_type,
+                           const char* file_name, uint8_t* ok_out, char* first_message, size_t first_message_cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TCRC_SHIM_H_ */

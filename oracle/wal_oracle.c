@@ -83,6 +83,11 @@ void oracle_sink_drop(void* s, size_t bytes) { /* StringSink::Drop */
   k->contents.n -= bytes;
   if (k->write_pos > k->contents.n) k->write_pos = k->contents.n;
 }
+void oracle_sink_append_raw(void* s, const void* data, size_t n) {
+  oracle_sink* k = (oracle_sink*)s;
+  bytes_append(&k->contents, data, n);
+  k->write_pos = k->contents.n;
+}
 void oracle_sink_rewind_for_overwrite(void* s) { ((oracle_sink*)s)->write_pos = 0; } /* OverwritingStringSink */
 static void sink_write(oracle_sink* k, const void* s, size_t n) {
   if (k->write_pos + n > k->contents.n) {

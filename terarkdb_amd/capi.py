@@ -43,6 +43,50 @@ SIGNATURES = {
     "tcrc_dev_batch_stamp": (_i, [_vp, _vp, _vp, _u64, _vp, _u32, _vp, _vp]),
     "tcrc_dev_batch_verify": (_i, [_vp, _vp, _vp, _u64, _vp, _u32, _vp, _vp, _vp, _vp, _vp]),
 }
+_sz = C.c_size_t
+STAMP_FN = C.CFUNCTYPE(_i, _vp, _vp, _sz, C.POINTER(Desc), _sz, C.POINTER(_u32))
+SCAN_FN = C.CFUNCTYPE(_i, _vp, _vp, _sz, _u64, C.POINTER(WalBlock))
+SIGNATURES.update({
+    "tcrc_host_alloc": (_vp, [_vp, _sz]),
+    "tcrc_host_free": (None, [_vp, _vp]),
+    "tcrc_host_batch_stamp": (_i, [_vp, _vp, _u64, _vp, _u64, _vp, _u32, _vp]),
+    "tcrc_host_blocks_stamp": (_i, [_vp, _vp, _u64, _u32, _u64, _u32, _i, _u32, _vp]),
+    "tcrc_host_batch_verify": (_i, [_vp, _vp, _u64, _vp, _u64, _vp, _u32, _vp, _vp, _vp, _vp]),
+    "tcrc_host_wal_verify": (_i, [_vp, _vp, _u64, _u64, _vp, _vp, C.POINTER(_u64)]),
+    "tcrc_shim_memfile_new": (_vp, []),
+    "tcrc_shim_memfile_free": (None, [_vp]),
+    "tcrc_shim_memfile_size": (_sz, [_vp]),
+    "tcrc_shim_memfile_data": (_vp, [_vp]),
+    "tcrc_shim_memfile_drop": (None, [_vp, _sz]),
+    "tcrc_shim_memfile_append": (None, [_vp, _vp, _sz]),
+    "tcrc_shim_wal_writer_new": (_vp, [_vp, _vp, _u64, _i, _i, _i]),
+    "tcrc_shim_wal_writer_new_cb": (_vp, [STAMP_FN, _vp, _vp, _u64, _i, _i, _i]),
+    "tcrc_shim_wal_writer_open": (_vp, [_vp, C.c_char_p, _u64, _i, _i]),
+    "tcrc_shim_wal_writer_add_record": (_i, [_vp, _vp, _sz]),
+    "tcrc_shim_wal_writer_write_buffer": (_i, [_vp]),
+    "tcrc_shim_wal_writer_status": (C.c_char_p, [_vp]),
+    "tcrc_shim_wal_writer_physical_records": (_u64, [_vp]),
+    "tcrc_shim_wal_writer_crc_bytes": (_u64, [_vp]),
+    "tcrc_shim_wal_writer_free": (None, [_vp]),
+    "tcrc_shim_wal_reader_new": (_vp, [_vp, _vp, _i, _u64, _i]),
+    "tcrc_shim_wal_reader_new_cb": (_vp, [SCAN_FN, _vp, _vp, _i, _u64, _i]),
+    "tcrc_shim_wal_reader_open": (_vp, [_vp, C.c_char_p, _i, _u64]),
+    "tcrc_shim_wal_reader_attach_image": (_i, [_vp, _vp, _sz]),
+    "tcrc_shim_wal_reader_read_record": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_sz)]),
+    "tcrc_shim_wal_reader_dropped_bytes": (_sz, [_vp]),
+    "tcrc_shim_wal_reader_report": (C.c_char_p, [_vp]),
+    "tcrc_shim_wal_reader_is_eof": (_i, [_vp]),
+    "tcrc_shim_wal_reader_unmark_eof": (None, [_vp]),
+    "tcrc_shim_wal_reader_last_record_offset": (_u64, [_vp]),
+    "tcrc_shim_wal_reader_verifier_calls": (_u64, [_vp]),
+    "tcrc_shim_wal_reader_force_error": (None, [_vp, _sz]),
+    "tcrc_shim_wal_reader_force_eof": (None, [_vp, _sz]),
+    "tcrc_shim_wal_reader_read_after_partial": (_i, [_vp]),
+    "tcrc_shim_wal_reader_free": (None, [_vp]),
+    "tcrc_shim_block_trailers": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _i, _vp]),
+    "tcrc_shim_write_raw_blocks": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp]),
+    "tcrc_shim_check_blocks": (_i, [_vp, _vp, _sz, _u64, _vp, _vp, _sz, _i, C.c_char_p, _vp, C.c_char_p, _sz]),
+})
 for _name, (_res, _args) in SIGNATURES.items():
     _f = getattr(lib, _name)
     _f.restype = _res

@@ -424,8 +424,10 @@ int tcrc_shutdown(tcrc_ctx* ctx) {
     if (ctx->d_tab_main[gi]) (void)hipFree(ctx->d_tab_main[gi]);
     if (ctx->d_tab_aux[gi]) (void)hipFree(ctx->d_tab_aux[gi]);
   }
-  for (tcrc_scratch* s : {&ctx->wal_counts, &ctx->wal_first, &ctx->wal_items, &ctx->wal_item_block, &ctx->wal_misc})
+  for (tcrc_scratch* s : {&ctx->wal_counts, &ctx->wal_first, &ctx->wal_items, &ctx->wal_item_block, &ctx->wal_misc,
+                          &ctx->host_data, &ctx->host_desc, &ctx->host_out, &ctx->host_aux, &ctx->host_blocks})
     scratch_release(s);
+  if (ctx->host_stream) (void)hipStreamDestroy(ctx->host_stream);
   delete ctx;
   return TCRC_OK;
 }

@@ -1,0 +1,157 @@
+// Host-pointer entry points: copy in, run the device path, copy the (small) results out.
+// The hot path of the reference starts and ends in host memory (log buffers, blocks read
+// through env/io_posix.cc), so these are what a host caller uses; their rate is bounded
+// by the host link, not by the kernels.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <string>
+
+#include "tcrc_internal.h"
+
+using namespace tcrc_internal;
+
+namespace {
+
+int host_begin(tcrc_ctx* ctx) {
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (!ctx->host_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->host_stream, hipStreamNonBlocking));
+  return TCRC_OK;
+}
+
+int upload(tcrc_ctx* ctx, tcrc_scratch* s, const void* h, size_t bytes, size_t slack = 64) {
+  if (int rc = scratch_reserve(ctx, s, bytes + slack)) return rc;
+  if (bytes) HIP_TRY(hipMemcpyAsync(s->p, h, bytes, hipMemcpyHostToDevice, ctx->host_stream));
+  return TCRC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void* tcrc_host_alloc(tcrc_ctx* ctx, size_t bytes) {
+  if (!ctx) return nullptr;
+  if (hipSetDevice(ctx->device) != hipSuccess) return nullptr;
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+  return p;
+}
+
+void tcrc_host_free(tcrc_ctx* ctx, void* p) {
+  (void)ctx;
+  if (p) (void)hipHostFree(p);
+}
+
+int tcrc_host_batch_stamp(tcrc_ctx* ctx, const void* h_base, uint64_t base_bytes, const tcrc_desc* h_desc, uint64_t n,
+                          const uint8_t* h_suffix, uint32_t flags, uint32_t* h_out) {
+  if (!ctx) return fail(TCRC_ERR_INVALID, "null context");
+  if (n == 0) return TCRC_OK;
+  if (!h_base || !h_desc || !h_out) return fail(TCRC_ERR_INVALID, "null argument");
+  for (uint64_t i = 0; i < n; ++i)
+    if (h_desc[i].offset + h_desc[i].len > base_bytes) return fail(TCRC_ERR_INVALID, "descriptor outside the buffer");
+  std::lock_guard<std::mutex> lock(ctx->host_mu);
+  if (int rc = host_begin(ctx)) return rc;
+  if (int rc = upload(ctx, &ctx->host_data, h_base, base_bytes)) return rc;
+  if (int rc = upload(ctx, &ctx->host_desc, h_desc, n * sizeof(tcrc_desc))) return rc;
+  if (h_suffix)
+    if (int rc = upload(ctx, &ctx->host_aux, h_suffix, n)) return rc;
+  if (int rc = scratch_reserve(ctx, &ctx->host_out, n * 4)) return rc;
+  if (int rc = tcrc_dev_batch_stamp(ctx, ctx->host_data.p, (const tcrc_desc*)ctx->host_desc.p, n,
+                                    h_suffix ? (const uint8_t*)ctx->host_aux.p : nullptr, flags,
+                                    (uint32_t*)ctx->host_out.p, ctx->host_stream))
+    return rc;
+  HIP_TRY(hipMemcpyAsync(h_out, ctx->host_out.p, n * 4, hipMemcpyDeviceToHost, ctx->host_stream));
+  HIP_TRY(hipStreamSynchronize(ctx->host_stream));
+  return TCRC_OK;
+}
+
+int tcrc_host_blocks_stamp(tcrc_ctx* ctx, const void* h_base, uint64_t n_blocks, uint32_t block_len, uint64_t stride,
+                           uint32_t init, int suffix_byte, uint32_t flags, uint32_t* h_out) {
+  if (!ctx) return fail(TCRC_ERR_INVALID, "null context");
+  if (n_blocks == 0) return TCRC_OK;
+  if (!h_base || !h_out) return fail(TCRC_ERR_INVALID, "null argument");
+  std::lock_guard<std::mutex> lock(ctx->host_mu);
+  if (int rc = host_begin(ctx)) return rc;
+  const uint64_t bytes = (n_blocks - 1) * stride + block_len;
+  if (int rc = upload(ctx, &ctx->host_data, h_base, bytes)) return rc;
+  if (int rc = scratch_reserve(ctx, &ctx->host_out, n_blocks * 4)) return rc;
+  if (int rc = tcrc_dev_blocks_stamp(ctx, ctx->host_data.p, n_blocks, block_len, stride, init, suffix_byte, nullptr,
+                                     flags, (uint32_t*)ctx->host_out.p, ctx->host_stream))
+    return rc;
+  HIP_TRY(hipMemcpyAsync(h_out, ctx->host_out.p, n_blocks * 4, hipMemcpyDeviceToHost, ctx->host_stream));
+  HIP_TRY(hipStreamSynchronize(ctx->host_stream));
+  return TCRC_OK;
+}
+
+int tcrc_host_batch_verify(tcrc_ctx* ctx, const void* h_base, uint64_t base_bytes, const tcrc_desc* h_desc, uint64_t n,
+                           const uint8_t* h_suffix, uint32_t flags, const uint32_t* h_expected, uint32_t* h_out,
+                           uint8_t* h_ok, uint64_t* h_counts) {
+  if (!ctx) return fail(TCRC_ERR_INVALID, "null context");
+  if (!h_counts) return fail(TCRC_ERR_INVALID, "verify needs a counts block");
+  h_counts[TCRC_CNT_MISMATCH] = 0;
+  h_counts[TCRC_CNT_FIRST_BAD] = ~0ull;
+  h_counts[TCRC_CNT_CHECKED] = 0;
+  if (n == 0) return TCRC_OK;
+  if (!h_base || !h_desc) return fail(TCRC_ERR_INVALID, "null argument");
+  const uint64_t after = (flags & TCRC_F_EXPECT_AFTER) ? 4 : 0;
+  for (uint64_t i = 0; i < n; ++i) {
+    if (h_desc[i].offset + h_desc[i].len + after > base_bytes)
+      return fail(TCRC_ERR_INVALID, "descriptor (or its stored checksum) outside the buffer");
+    if ((flags & TCRC_F_EXPECT_BEFORE) && h_desc[i].offset < 6)
+      return fail(TCRC_ERR_INVALID, "descriptor leaves no room for the stored checksum before it");
+  }
+  std::lock_guard<std::mutex> lock(ctx->host_mu);
+  if (int rc = host_begin(ctx)) return rc;
+  if (int rc = upload(ctx, &ctx->host_data, h_base, base_bytes)) return rc;
+  if (int rc = upload(ctx, &ctx->host_desc, h_desc, n * sizeof(tcrc_desc))) return rc;
+  // host_aux layout: [counts 3 x u64][suffix n][pad][expected n x u32][ok n]
+  const size_t off_suffix = 32, off_expected = (off_suffix + n + 15) & ~(size_t)15, off_ok = off_expected + n * 4;
+  if (int rc = scratch_reserve(ctx, &ctx->host_aux, off_ok + n + 64)) return rc;
+  uint8_t* aux = (uint8_t*)ctx->host_aux.p;
+  if (h_suffix) HIP_TRY(hipMemcpyAsync(aux + off_suffix, h_suffix, n, hipMemcpyHostToDevice, ctx->host_stream));
+  if (h_expected)
+    HIP_TRY(hipMemcpyAsync(aux + off_expected, h_expected, n * 4, hipMemcpyHostToDevice, ctx->host_stream));
+  if (int rc = scratch_reserve(ctx, &ctx->host_out, n * 4)) return rc;
+  if (int rc = tcrc_dev_counts_reset(ctx, (uint64_t*)aux, ctx->host_stream)) return rc;
+  if (int rc = tcrc_dev_batch_verify(ctx, ctx->host_data.p, (const tcrc_desc*)ctx->host_desc.p, n,
+                                     h_suffix ? aux + off_suffix : nullptr, flags,
+                                     h_expected ? (const uint32_t*)(aux + off_expected) : nullptr,
+                                     (uint32_t*)ctx->host_out.p, aux + off_ok, (uint64_t*)aux, ctx->host_stream))
+    return rc;
+  if (h_out) HIP_TRY(hipMemcpyAsync(h_out, ctx->host_out.p, n * 4, hipMemcpyDeviceToHost, ctx->host_stream));
+  if (h_ok) HIP_TRY(hipMemcpyAsync(h_ok, aux + off_ok, n, hipMemcpyDeviceToHost, ctx->host_stream));
+  HIP_TRY(hipMemcpyAsync(h_counts, aux, 24, hipMemcpyDeviceToHost, ctx->host_stream));
+  HIP_TRY(hipStreamSynchronize(ctx->host_stream));
+  return TCRC_OK;
+}
+
+int tcrc_host_wal_verify(tcrc_ctx* ctx, const void* h_img, uint64_t size, uint64_t log_number,
+                         tcrc_wal_block* h_blocks, uint64_t* h_counts, uint64_t* h_records) {
+  if (!ctx) return fail(TCRC_ERR_INVALID, "null context");
+  if (h_records) *h_records = 0;
+  if (h_counts) {
+    h_counts[TCRC_CNT_MISMATCH] = 0;
+    h_counts[TCRC_CNT_FIRST_BAD] = ~0ull;
+    h_counts[TCRC_CNT_CHECKED] = 0;
+  }
+  if (size == 0) return TCRC_OK;
+  if (!h_img || !h_blocks) return fail(TCRC_ERR_INVALID, "null argument");
+  std::lock_guard<std::mutex> lock(ctx->host_mu);
+  if (int rc = host_begin(ctx)) return rc;
+  const uint64_t nblocks = (size + 32767) / 32768;
+  if (int rc = upload(ctx, &ctx->host_data, h_img, size)) return rc;
+  if (int rc = scratch_reserve(ctx, &ctx->host_blocks, nblocks * sizeof(tcrc_wal_block))) return rc;
+  if (int rc = scratch_reserve(ctx, &ctx->host_aux, 64)) return rc;
+  if (int rc = tcrc_dev_counts_reset(ctx, (uint64_t*)ctx->host_aux.p, ctx->host_stream)) return rc;
+  if (int rc = tcrc_dev_wal_verify(ctx, ctx->host_data.p, size, log_number, (tcrc_wal_block*)ctx->host_blocks.p,
+                                   (uint64_t*)ctx->host_aux.p, h_records, ctx->host_stream))
+    return rc;
+  HIP_TRY(hipMemcpyAsync(h_blocks, ctx->host_blocks.p, nblocks * sizeof(tcrc_wal_block), hipMemcpyDeviceToHost,
+                         ctx->host_stream));
+  if (h_counts) HIP_TRY(hipMemcpyAsync(h_counts, ctx->host_aux.p, 24, hipMemcpyDeviceToHost, ctx->host_stream));
+  HIP_TRY(hipStreamSynchronize(ctx->host_stream));
+  return TCRC_OK;
+}
+
+}  // extern "C"

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
 #include <string>
 
 #include "../../include/tcrc.h"
@@ -66,6 +67,10 @@ struct tcrc_ctx {
   std::string description;
   // log-scan scratch (tcrc_wal.hip)
   tcrc_scratch wal_counts, wal_first, wal_items, wal_item_block, wal_misc;
+  // host-pointer entry points (tcrc_host.hip): their own stream and staging, one call at a time
+  std::mutex host_mu;
+  hipStream_t host_stream = nullptr;
+  tcrc_scratch host_data, host_desc, host_out, host_aux, host_blocks;
 };
 
 namespace tcrc_internal {

@@ -1,0 +1,102 @@
+#include "block_trailer.h"
+
+#include <string.h>
+
+namespace terarkdb_amd {
+
+namespace {
+Status EngineError() { return Status::IOError(std::string("checksum engine: ") + tcrc_last_error()); }
+}  // namespace
+
+Status ComputeBlockTrailers(tcrc_ctx* ctx, const std::vector<Slice>& contents, const std::vector<char>& types,
+                            ChecksumType checksum, std::vector<std::string>* trailers) {
+  if (contents.size() != types.size()) return Status::InvalidArgument("contents and types differ in length");
+  const size_t n = contents.size();
+  trailers->assign(n, std::string(kBlockTrailerSize, '\0'));
+  for (size_t i = 0; i < n; ++i) (*trailers)[i][0] = types[i];
+  if (checksum == kNoChecksum || n == 0) return Status::OK();  // checksum field stays zero
+  if (checksum != kCRC32c) return Status::NotSupported("block checksum type is not CRC32c");
+  // Gather into one staging buffer: block bytes followed by the type byte, so the covered
+  // span of block i is contiguous (Value(block) extended by the type, builder :599-600).
+  size_t total = 0;
+  for (const Slice& c : contents) total += c.size() + 1;
+  char* stage = static_cast<char*>(tcrc_host_alloc(ctx, total));
+  if (!stage) return EngineError();
+  std::vector<tcrc_desc> spans(n);
+  size_t pos = 0;
+  for (size_t i = 0; i < n; ++i) {
+    if (contents[i].size() >= 0xffffffffull) {
+      tcrc_host_free(ctx, stage);
+      return Status::InvalidArgument("block too large");
+    }
+    if (contents[i].size()) memcpy(stage + pos, contents[i].data(), contents[i].size());
+    stage[pos + contents[i].size()] = types[i];
+    spans[i].offset = pos;
+    spans[i].len = static_cast<uint32_t>(contents[i].size() + 1);
+    spans[i].init = 0;
+    pos += contents[i].size() + 1;
+  }
+  std::vector<uint32_t> masked(n);
+  int rc = tcrc_host_batch_stamp(ctx, stage, total, spans.data(), n, nullptr, TCRC_F_MASK, masked.data());
+  tcrc_host_free(ctx, stage);
+  if (rc != TCRC_OK) return EngineError();
+  for (size_t i = 0; i < n; ++i) EncodeFixed32(&(*trailers)[i][1], masked[i]);
+  return Status::OK();
+}
+
+Status WriteRawBlocks(tcrc_ctx* ctx, WritableFile* file, uint64_t* file_offset, const std::vector<Slice>& contents,
+                      const std::vector<char>& types, ChecksumType checksum, std::vector<BlockHandle>* handles) {
+  std::vector<std::string> trailers;
+  Status s = ComputeBlockTrailers(ctx, contents, types, checksum, &trailers);
+  if (!s.ok()) return s;
+  handles->clear();
+  for (size_t i = 0; i < contents.size(); ++i) {
+    BlockHandle h;
+    h.offset = *file_offset;
+    h.size = contents[i].size();
+    s = file->Append(contents[i]);
+    if (s.ok()) s = file->Append(Slice(trailers[i]));
+    if (!s.ok()) return s;
+    handles->push_back(h);
+    *file_offset += contents[i].size() + kBlockTrailerSize;
+  }
+  return Status::OK();
+}
+
+Status CheckBlockChecksums(tcrc_ctx* ctx, const Slice& image, uint64_t image_file_offset,
+                           const std::vector<BlockHandle>& handles, ChecksumType footer_checksum,
+                           const std::string& file_name, std::vector<Status>* statuses) {
+  const size_t n = handles.size();
+  statuses->assign(n, Status::OK());
+  if (footer_checksum == kNoChecksum || n == 0) return Status::OK();
+  if (footer_checksum != kCRC32c) return Status::NotSupported("block checksum type is not CRC32c");
+  std::vector<tcrc_desc> spans(n);
+  for (size_t i = 0; i < n; ++i) {
+    const BlockHandle& h = handles[i];
+    if (h.offset < image_file_offset || h.offset - image_file_offset + h.size + kBlockTrailerSize > image.size())
+      return Status::InvalidArgument("block handle outside the image");
+    spans[i].offset = h.offset - image_file_offset;
+    spans[i].len = static_cast<uint32_t>(h.size + 1);  // contents and type byte (fetcher :48)
+    spans[i].init = 0;
+  }
+  std::vector<uint32_t> computed(n);
+  std::vector<uint8_t> ok(n);
+  uint64_t counts[TCRC_CNT_WORDS];
+  int rc = tcrc_host_batch_verify(ctx, image.data(), image.size(), spans.data(), n, nullptr, TCRC_F_EXPECT_AFTER,
+                                  nullptr, computed.data(), ok.data(), counts);
+  if (rc != TCRC_OK) return EngineError();
+  Status first;
+  for (size_t i = 0; i < n; ++i) {
+    if (ok[i]) continue;
+    const BlockHandle& h = handles[i];
+    const uint32_t stored = tcrc_unmask(DecodeFixed32(image.data() + spans[i].offset + h.size + 1));
+    const uint32_t actual = tcrc_unmask(computed[i]);
+    (*statuses)[i] = Status::Corruption("block checksum mismatch: expected " + std::to_string(actual) + ", got " +
+                                        std::to_string(stored) + "  in " + file_name + " offset " +
+                                        std::to_string(h.offset) + " size " + std::to_string(h.size));
+    if (first.ok()) first = (*statuses)[i];
+  }
+  return first;
+}
+
+}  // namespace terarkdb_amd

@@ -1,0 +1,273 @@
+// C entry points over the C++ writer/reader/trailer classes, so that bindings and tests
+// can drive them without a C++ compiler.  Declared in include/tcrc_shim.h.
+#include <string.h>
+
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/tcrc_shim.h"
+#include "block_trailer.h"
+#include "files.h"
+#include "wal_reader.h"
+#include "wal_writer.h"
+
+using namespace terarkdb_amd;
+
+namespace {
+
+struct MemFileBox {
+  std::shared_ptr<MemFile> file = std::make_shared<MemFile>();
+};
+
+class CallbackStamper : public log::RecordStamper {
+ public:
+  CallbackStamper(tcrc_shim_stamp_fn fn, void* user) : fn_(fn), user_(user) {}
+  Status Stamp(const char* base, size_t base_bytes, const tcrc_desc* spans, size_t n, uint32_t* out) override {
+    if (fn_(user_, base, base_bytes, spans, n, out) != 0) return Status::IOError("stamp callback failed");
+    return Status::OK();
+  }
+
+ private:
+  tcrc_shim_stamp_fn fn_;
+  void* user_;
+};
+
+class CallbackVerifier : public log::RecordVerifier {
+ public:
+  CallbackVerifier(tcrc_shim_scan_fn fn, void* user) : fn_(fn), user_(user) {}
+  Status ScanBlocks(const char* img, size_t n, uint64_t log_number, tcrc_wal_block* blocks) override {
+    if (fn_(user_, img, n, log_number, blocks) != 0) return Status::IOError("scan callback failed");
+    return Status::OK();
+  }
+
+ private:
+  tcrc_shim_scan_fn fn_;
+  void* user_;
+};
+
+struct WriterBox {
+  std::unique_ptr<log::RecordStamper> stamper;
+  MemSink* sink = nullptr;  // owned by the writer
+  std::unique_ptr<log::Writer> writer;
+  std::string last_status;
+};
+
+class CollectingReporter : public log::Reader::Reporter {
+ public:
+  size_t dropped_bytes = 0;
+  std::string message;
+  void Corruption(size_t bytes, const Status& status) override {
+    dropped_bytes += bytes;
+    message.append(status.ToString());
+  }
+};
+
+struct ReaderBox {
+  std::unique_ptr<log::RecordVerifier> verifier;
+  CollectingReporter report;
+  MemSource* source = nullptr;  // owned by the reader
+  std::unique_ptr<log::Reader> reader;
+  std::string scratch;
+  std::shared_ptr<MemFile> file;
+  uint64_t log_number = 0;
+};
+
+WriterBox* make_writer(std::unique_ptr<log::RecordStamper> st, std::unique_ptr<WritableFile> dest, MemSink* sink,
+                       uint64_t log_number, int recycle, int manual_flush) {
+  WriterBox* b = new WriterBox();
+  b->stamper = std::move(st);
+  b->sink = sink;
+  b->writer.reset(new log::Writer(std::move(dest), log_number, recycle != 0, manual_flush != 0, b->stamper.get()));
+  return b;
+}
+
+}  // namespace
+
+extern "C" {
+
+void* tcrc_shim_memfile_new(void) { return new MemFileBox(); }
+void tcrc_shim_memfile_free(void* f) { delete static_cast<MemFileBox*>(f); }
+size_t tcrc_shim_memfile_size(void* f) { return static_cast<MemFileBox*>(f)->file->contents.size(); }
+char* tcrc_shim_memfile_data(void* f) {
+  std::string& c = static_cast<MemFileBox*>(f)->file->contents;
+  return c.empty() ? nullptr : &c[0];
+}
+void tcrc_shim_memfile_drop(void* f, size_t bytes) {
+  std::string& c = static_cast<MemFileBox*>(f)->file->contents;
+  c.resize(c.size() - bytes);
+}
+void tcrc_shim_memfile_append(void* f, const void* data, size_t n) {
+  static_cast<MemFileBox*>(f)->file->contents.append(static_cast<const char*>(data), n);
+}
+
+void* tcrc_shim_wal_writer_new(tcrc_ctx* ctx, void* memfile, uint64_t log_number, int recycle, int manual_flush,
+                               int overwrite) {
+  MemSink* sink = new MemSink(static_cast<MemFileBox*>(memfile)->file, overwrite != 0);
+  return make_writer(std::unique_ptr<log::RecordStamper>(new log::DeviceRecordStamper(ctx)),
+                     std::unique_ptr<WritableFile>(sink), sink, log_number, recycle, manual_flush);
+}
+
+void* tcrc_shim_wal_writer_new_cb(tcrc_shim_stamp_fn fn, void* user, void* memfile, uint64_t log_number, int recycle,
+                                  int manual_flush, int overwrite) {
+  MemSink* sink = new MemSink(static_cast<MemFileBox*>(memfile)->file, overwrite != 0);
+  return make_writer(std::unique_ptr<log::RecordStamper>(new CallbackStamper(fn, user)),
+                     std::unique_ptr<WritableFile>(sink), sink, log_number, recycle, manual_flush);
+}
+
+void* tcrc_shim_wal_writer_open(tcrc_ctx* ctx, const char* path, uint64_t log_number, int recycle, int manual_flush) {
+  std::unique_ptr<WritableFile> f;
+  if (!NewPosixWritableFile(path, &f).ok()) return nullptr;
+  return make_writer(std::unique_ptr<log::RecordStamper>(new log::DeviceRecordStamper(ctx)), std::move(f), nullptr,
+                     log_number, recycle, manual_flush);
+}
+
+int tcrc_shim_wal_writer_add_record(void* w, const void* data, size_t n) {
+  WriterBox* b = static_cast<WriterBox*>(w);
+  Status s = b->writer->AddRecord(Slice(static_cast<const char*>(data), n));
+  b->last_status = s.ToString();
+  return s.ok() ? 0 : -1;
+}
+int tcrc_shim_wal_writer_write_buffer(void* w) {
+  WriterBox* b = static_cast<WriterBox*>(w);
+  Status s = b->writer->WriteBuffer();
+  b->last_status = s.ToString();
+  return s.ok() ? 0 : -1;
+}
+const char* tcrc_shim_wal_writer_status(void* w) { return static_cast<WriterBox*>(w)->last_status.c_str(); }
+uint64_t tcrc_shim_wal_writer_physical_records(void* w) { return static_cast<WriterBox*>(w)->writer->physical_records(); }
+uint64_t tcrc_shim_wal_writer_crc_bytes(void* w) { return static_cast<WriterBox*>(w)->writer->crc_bytes(); }
+void tcrc_shim_wal_writer_free(void* w) { delete static_cast<WriterBox*>(w); }
+
+static ReaderBox* make_reader(std::unique_ptr<log::RecordVerifier> v, void* memfile, int checksum, uint64_t log_number,
+                              int retry_after_eof) {
+  ReaderBox* b = new ReaderBox();
+  b->verifier = std::move(v);
+  b->file = static_cast<MemFileBox*>(memfile)->file;
+  b->log_number = log_number;
+  b->source = new MemSource(b->file);
+  b->reader.reset(new log::Reader(std::unique_ptr<SequentialFile>(b->source), &b->report, checksum != 0, log_number,
+                                  retry_after_eof != 0, b->verifier.get()));
+  return b;
+}
+
+void* tcrc_shim_wal_reader_new(tcrc_ctx* ctx, void* memfile, int checksum, uint64_t log_number, int retry_after_eof) {
+  return make_reader(std::unique_ptr<log::RecordVerifier>(new log::DeviceRecordVerifier(ctx)), memfile, checksum,
+                     log_number, retry_after_eof);
+}
+
+void* tcrc_shim_wal_reader_new_cb(tcrc_shim_scan_fn fn, void* user, void* memfile, int checksum, uint64_t log_number,
+                                  int retry_after_eof) {
+  return make_reader(std::unique_ptr<log::RecordVerifier>(new CallbackVerifier(fn, user)), memfile, checksum,
+                     log_number, retry_after_eof);
+}
+
+void* tcrc_shim_wal_reader_open(tcrc_ctx* ctx, const char* path, int checksum, uint64_t log_number) {
+  std::unique_ptr<SequentialFile> f;
+  if (!NewPosixSequentialFile(path, &f).ok()) return nullptr;
+  ReaderBox* b = new ReaderBox();
+  b->verifier.reset(new log::DeviceRecordVerifier(ctx));
+  b->log_number = log_number;
+  b->reader.reset(new log::Reader(std::move(f), &b->report, checksum != 0, log_number, false, b->verifier.get()));
+  return b;
+}
+
+int tcrc_shim_wal_reader_attach_image(void* r, const void* img, size_t n) {
+  ReaderBox* b = static_cast<ReaderBox*>(r);
+  auto image = std::make_shared<log::VerifiedLogImage>();
+  const char* p = static_cast<const char*>(img);
+  if (!p) {
+    p = b->file->contents.data();
+    n = b->file->contents.size();
+  }
+  Status s = log::VerifyLogImage(b->verifier.get(), p, n, b->log_number, image.get());
+  if (!s.ok()) return -1;
+  b->reader->AttachVerifiedImage(image);
+  return 0;
+}
+
+int tcrc_shim_wal_reader_read_record(void* r, int mode, const char** rec, size_t* n) {
+  ReaderBox* b = static_cast<ReaderBox*>(r);
+  Slice record;
+  bool ok = b->reader->ReadRecord(&record, &b->scratch, static_cast<WALRecoveryMode>(mode));
+  *rec = record.data();
+  *n = record.size();
+  return ok ? 1 : 0;
+}
+size_t tcrc_shim_wal_reader_dropped_bytes(void* r) { return static_cast<ReaderBox*>(r)->report.dropped_bytes; }
+const char* tcrc_shim_wal_reader_report(void* r) { return static_cast<ReaderBox*>(r)->report.message.c_str(); }
+int tcrc_shim_wal_reader_is_eof(void* r) { return static_cast<ReaderBox*>(r)->reader->IsEOF() ? 1 : 0; }
+void tcrc_shim_wal_reader_unmark_eof(void* r) {
+  ReaderBox* b = static_cast<ReaderBox*>(r);
+  if (b->source) b->source->ClearPartial();
+  b->reader->UnmarkEOF();
+}
+uint64_t tcrc_shim_wal_reader_last_record_offset(void* r) {
+  return static_cast<ReaderBox*>(r)->reader->LastRecordOffset();
+}
+uint64_t tcrc_shim_wal_reader_verifier_calls(void* r) { return static_cast<ReaderBox*>(r)->reader->verifier_calls(); }
+void tcrc_shim_wal_reader_force_error(void* r, size_t position) {
+  static_cast<ReaderBox*>(r)->source->ForceError(position);
+}
+void tcrc_shim_wal_reader_force_eof(void* r, size_t position) { static_cast<ReaderBox*>(r)->source->ForceEOF(position); }
+int tcrc_shim_wal_reader_read_after_partial(void* r) {
+  return static_cast<ReaderBox*>(r)->source->read_after_partial() ? 1 : 0;
+}
+void tcrc_shim_wal_reader_free(void* r) { delete static_cast<ReaderBox*>(r); }
+
+int tcrc_shim_block_trailers(tcrc_ctx* ctx, const void* base, const uint64_t* offsets, const uint64_t* sizes,
+                             const uint8_t* types, size_t n, int checksum_type, uint8_t* trailers_out) {
+  std::vector<Slice> contents(n);
+  std::vector<char> t(n);
+  for (size_t i = 0; i < n; ++i) {
+    contents[i] = Slice(static_cast<const char*>(base) + offsets[i], sizes[i]);
+    t[i] = static_cast<char>(types[i]);
+  }
+  std::vector<std::string> trailers;
+  Status s = ComputeBlockTrailers(ctx, contents, t, static_cast<ChecksumType>(checksum_type), &trailers);
+  if (!s.ok()) return s.code() == Status::kNotSupported ? -2 : -1;
+  for (size_t i = 0; i < n; ++i) memcpy(trailers_out + 5 * i, trailers[i].data(), 5);
+  return 0;
+}
+
+int tcrc_shim_write_raw_blocks(tcrc_ctx* ctx, void* memfile, const void* base, const uint64_t* offsets,
+                               const uint64_t* sizes, const uint8_t* types, size_t n, int checksum_type,
+                               uint64_t* handle_offsets_out) {
+  std::vector<Slice> contents(n);
+  std::vector<char> t(n);
+  for (size_t i = 0; i < n; ++i) {
+    contents[i] = Slice(static_cast<const char*>(base) + offsets[i], sizes[i]);
+    t[i] = static_cast<char>(types[i]);
+  }
+  MemSink sink(static_cast<MemFileBox*>(memfile)->file);
+  uint64_t off = static_cast<MemFileBox*>(memfile)->file->contents.size();
+  std::vector<BlockHandle> handles;
+  Status s = WriteRawBlocks(ctx, &sink, &off, contents, t, static_cast<ChecksumType>(checksum_type), &handles);
+  if (!s.ok()) return s.code() == Status::kNotSupported ? -2 : -1;
+  for (size_t i = 0; i < n; ++i) handle_offsets_out[i] = handles[i].offset;
+  return 0;
+}
+
+int tcrc_shim_check_blocks(tcrc_ctx* ctx, const void* image, size_t image_size, uint64_t image_file_offset,
+                           const uint64_t* handle_offsets, const uint64_t* handle_sizes, size_t n, int checksum_type,
+                           const char* file_name, uint8_t* ok_out, char* first_message, size_t first_message_cap) {
+  std::vector<BlockHandle> handles(n);
+  for (size_t i = 0; i < n; ++i) {
+    handles[i].offset = handle_offsets[i];
+    handles[i].size = handle_sizes[i];
+  }
+  std::vector<Status> st;
+  Status first = CheckBlockChecksums(ctx, Slice(static_cast<const char*>(image), image_size), image_file_offset, handles,
+                                     static_cast<ChecksumType>(checksum_type), file_name ? file_name : "", &st);
+  if (first.code() == Status::kNotSupported) return -2;
+  if (!first.ok() && !first.IsCorruption()) return -1;
+  for (size_t i = 0; i < n && ok_out; ++i) ok_out[i] = st[i].ok() ? 1 : 0;
+  if (first_message && first_message_cap) {
+    std::string m = first.ok() ? "" : first.ToString();
+    strncpy(first_message, m.c_str(), first_message_cap - 1);
+    first_message[first_message_cap - 1] = 0;
+  }
+  return first.ok() ? 0 : 1;
+}
+
+}  // extern "C"

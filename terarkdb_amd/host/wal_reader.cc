@@ -1,0 +1,319 @@
+#include "wal_reader.h"
+
+#include <stdio.h>
+#include <string.h>
+
+namespace terarkdb_amd {
+namespace log {
+
+Reader::Reader(std::unique_ptr<SequentialFile>&& file, Reporter* reporter, bool checksum, uint64_t log_num,
+               bool retry_after_eof, RecordVerifier* verifier)
+    : file_(std::move(file)),
+      reporter_(reporter),
+      checksum_(checksum),
+      backing_store_(new char[kBlockSize]),
+      buffer_(),
+      eof_(false),
+      read_error_(false),
+      eof_offset_(0),
+      last_record_offset_(0),
+      end_of_buffer_offset_(0),
+      log_number_(log_num),
+      recycled_(false),
+      retry_after_eof_(retry_after_eof),
+      verifier_(verifier),
+      verdict_known_(false),
+      first_bad_(0xffffffffu),
+      next_index_(0),
+      verifier_calls_(0) {}
+
+Reader::~Reader() { delete[] backing_store_; }
+
+void Reader::Drop(size_t bytes, const Status& why) {
+  if (reporter_ != nullptr) reporter_->Corruption(bytes, why);
+}
+
+// buffer_ now holds different bytes: whatever was known about its checksums is void.
+// Record indices count from the start of the 32 KiB block.
+void Reader::BufferChanged(bool new_block) {
+  verdict_known_ = false;
+  first_bad_ = 0xffffffffu;
+  if (new_block) next_index_ = 0;
+}
+
+// Is the checksum of the record at the front of buffer_ good?  (The comparison the
+// reference makes at db/log_reader.cc:388-390, answered by the engine.)
+bool Reader::ChecksumGood() {
+  if (!verdict_known_) {
+    // buffer_ never spans two blocks, so its last byte names the block
+    const uint64_t block = (end_of_buffer_offset_ - 1) / kBlockSize;
+    bool from_image = false;
+    if (image_ && end_of_buffer_offset_ <= image_->size && block < image_->blocks.size()) {
+      // every byte of buffer_ was in the verified image, whose walk of this block met the
+      // same records in the same order
+      first_bad_ = image_->blocks[block].first_bad;
+      from_image = true;
+    }
+    if (!from_image) {
+      tcrc_wal_block one;
+      memset(&one, 0, sizeof(one));
+      one.first_bad = 0xffffffffu;
+      Status s = verifier_ ? verifier_->ScanBlocks(buffer_.data(), buffer_.size(), log_number_, &one)
+                           : Status::NotSupported("log reader has no checksum verifier");
+      ++verifier_calls_;
+      if (!s.ok()) {
+        // an engine failure must not pass for a good checksum
+        Drop(0, s);
+        first_bad_ = next_index_;
+      } else {
+        // the scan counted from the front of buffer_
+        first_bad_ = one.first_bad == 0xffffffffu ? one.first_bad : next_index_ + one.first_bad;
+      }
+    }
+    verdict_known_ = true;
+  }
+  return next_index_ != first_bad_;
+}
+
+// Brings more bytes into buffer_ (db/log_reader.cc:276-312).
+bool Reader::Refill(size_t* drop_size, int* error) {
+  if (!eof_ && !read_error_) {
+    buffer_.clear();
+    Status status = file_->Read(kBlockSize, &buffer_, backing_store_);
+    end_of_buffer_offset_ += buffer_.size();
+    BufferChanged(true);
+    if (!status.ok()) {
+      buffer_.clear();
+      Drop(kBlockSize, status);
+      read_error_ = true;
+      *error = kEof;
+      return false;
+    }
+    if (buffer_.size() < static_cast<size_t>(kBlockSize)) {
+      eof_ = true;
+      eof_offset_ = buffer_.size();
+    }
+    return true;
+  }
+  if (retry_after_eof_ && !read_error_) {
+    UnmarkEOF();
+    return !read_error_;
+  }
+  // A non-empty rest here is a header cut short at the end of the file: the writer may
+  // have died while writing it.  Reported only when the caller asks for it.
+  if (buffer_.size()) {
+    *drop_size = buffer_.size();
+    buffer_.clear();
+    *error = kBadHeader;
+    return false;
+  }
+  buffer_.clear();
+  *error = kEof;
+  return false;
+}
+
+// After an end of file in the middle of a block: read the rest of that block
+// (db/log_reader.cc:202-264).
+void Reader::UnmarkEOF() {
+  if (read_error_) return;
+  eof_ = false;
+  if (!retry_after_eof_ && eof_offset_ == 0) return;
+
+  const size_t consumed = eof_offset_ - buffer_.size();
+  const size_t want = kBlockSize - eof_offset_;
+  if (buffer_.data() != backing_store_ + consumed) {
+    memmove(backing_store_ + consumed, buffer_.data(), buffer_.size());
+  }
+  Slice got;
+  Status status = file_->Read(want, &got, backing_store_ + eof_offset_);
+  const size_t added = got.size();
+  end_of_buffer_offset_ += added;
+  if (!status.ok()) {
+    if (added > 0) Drop(added, status);
+    read_error_ = true;
+    return;
+  }
+  if (got.data() != backing_store_ + eof_offset_) memmove(backing_store_ + eof_offset_, got.data(), added);
+  buffer_ = Slice(backing_store_ + consumed, eof_offset_ + added - consumed);
+  if (added > 0) {
+    // the records still in front keep their places, but new ones may have arrived: ask again
+    BufferChanged(false);
+  }
+  if (added < want) {
+    eof_ = true;
+    eof_offset_ += added;
+  } else {
+    eof_offset_ = 0;
+  }
+}
+
+// One physical record (db/log_reader.cc:314-406).
+unsigned int Reader::NextPhysical(Slice* payload, size_t* drop_size) {
+  for (;;) {
+    if (buffer_.size() < static_cast<size_t>(kHeaderSize)) {
+      int why = kEof;
+      if (!Refill(drop_size, &why)) return why;
+      continue;
+    }
+    const char* header = buffer_.data();
+    const uint32_t length = (static_cast<uint32_t>(header[4]) & 0xff) | ((static_cast<uint32_t>(header[5]) & 0xff) << 8);
+    const unsigned int type = header[6];  // through char, as the reference does
+    size_t header_size = kHeaderSize;
+    if (type >= kRecyclableFullType && type <= kRecyclableLastType) {
+      if (end_of_buffer_offset_ - buffer_.size() == 0) recycled_ = true;
+      header_size = kRecyclableHeaderSize;
+      if (buffer_.size() < header_size) {
+        int why = kEof;
+        if (!Refill(drop_size, &why)) return why;
+        continue;
+      }
+      if (static_cast<uint64_t>(DecodeFixed32(header + 7)) != log_number_) return kOldRecord;
+    }
+    if (header_size + length > buffer_.size()) {
+      if (retry_after_eof_) {
+        int why = kEof;
+        if (!Refill(drop_size, &why)) return why;
+        continue;
+      }
+      *drop_size = buffer_.size();
+      buffer_.clear();
+      if (!eof_) return kBadRecordLen;
+      // the file ends before the payload does: the writer presumably died mid-record
+      return *drop_size ? kBadHeader : kEof;
+    }
+    if (type == kZeroType && length == 0) {
+      // preallocated file space; skipped without a report
+      buffer_.clear();
+      return kBadRecord;
+    }
+    if (checksum_ && !ChecksumGood()) {
+      // "length" itself may be what is corrupt, so nothing after this record in the block is trusted
+      *drop_size = buffer_.size();
+      buffer_.clear();
+      return kBadRecordChecksum;
+    }
+    ++next_index_;
+    buffer_.remove_prefix(header_size + length);
+    *payload = Slice(header + header_size, length);
+    return type;
+  }
+}
+
+// Reassembly and recovery-mode policy (db/log_reader.cc:54-198).
+bool Reader::ReadRecord(Slice* record, std::string* scratch, WALRecoveryMode mode) {
+  scratch->clear();
+  record->clear();
+  bool assembling = false;       // a FIRST fragment has been seen and its LAST has not
+  uint64_t record_start = 0;     // file offset of the logical record being assembled
+  const bool strict = mode == WALRecoveryMode::kAbsoluteConsistency;
+
+  // An interrupted logical record at a point where the log legitimately may end.
+  auto abandon_tail = [&]() {
+    if (assembling) {
+      if (strict) DropCorrupt(scratch->size(), "error reading trailing data");
+      scratch->clear();
+    }
+  };
+  // A hole in the middle of the log: whatever was being assembled is lost.
+  auto abandon_middle = [&]() {
+    if (assembling) {
+      DropCorrupt(scratch->size(), "error in middle of record");
+      assembling = false;
+      scratch->clear();
+    }
+  };
+
+  Slice fragment;
+  for (;;) {
+    const uint64_t physical_offset = end_of_buffer_offset_ - buffer_.size();
+    size_t drop_size = 0;
+    const unsigned int what = NextPhysical(&fragment, &drop_size);
+
+    if (what == kFullType || what == kRecyclableFullType || what == kFirstType || what == kRecyclableFirstType) {
+      const bool whole = (what == kFullType || what == kRecyclableFullType);
+      if (assembling && !scratch->empty()) {
+        // old writers could leave an empty FIRST at the end of a block before restarting the record
+        DropCorrupt(scratch->size(), whole ? "partial record without end(1)" : "partial record without end(2)");
+      }
+      record_start = physical_offset;
+      if (whole) {
+        scratch->clear();
+        *record = fragment;
+        last_record_offset_ = record_start;
+        return true;
+      }
+      scratch->assign(fragment.data(), fragment.size());
+      assembling = true;
+      continue;
+    }
+
+    if (what == kMiddleType || what == kRecyclableMiddleType || what == kLastType || what == kRecyclableLastType) {
+      const bool closes = (what == kLastType || what == kRecyclableLastType);
+      if (!assembling) {
+        DropCorrupt(fragment.size(),
+                    closes ? "missing start of fragmented record(2)" : "missing start of fragmented record(1)");
+        continue;
+      }
+      scratch->append(fragment.data(), fragment.size());
+      if (closes) {
+        *record = Slice(*scratch);
+        last_record_offset_ = record_start;
+        return true;
+      }
+      continue;
+    }
+
+    switch (what) {
+      case kBadHeader:
+        if (strict) DropCorrupt(drop_size, "truncated header");
+        abandon_tail();
+        return false;
+      case kEof:
+        abandon_tail();
+        return false;
+      case kOldRecord:
+        if (mode != WALRecoveryMode::kSkipAnyCorruptedRecords) {
+          // a record from the file's previous life marks the end of this log
+          abandon_tail();
+          return false;
+        }
+        abandon_middle();
+        break;
+      case kBadRecord:
+        abandon_middle();
+        break;
+      case kBadRecordLen:
+      case kBadRecordChecksum:
+        if (recycled_ && mode == WALRecoveryMode::kTolerateCorruptedTailRecords) {
+          scratch->clear();
+          return false;
+        }
+        DropCorrupt(drop_size, what == kBadRecordLen ? "bad record length" : "checksum mismatch");
+        abandon_middle();
+        break;
+      default: {
+        char msg[40];
+        snprintf(msg, sizeof(msg), "unknown record type %u", what);
+        DropCorrupt(fragment.size() + (assembling ? scratch->size() : 0), msg);
+        assembling = false;
+        scratch->clear();
+        break;
+      }
+    }
+  }
+}
+
+Status VerifyLogImage(RecordVerifier* verifier, const char* img, size_t n, uint64_t log_number,
+                      VerifiedLogImage* out) {
+  out->size = n;
+  out->blocks.assign((n + kBlockSize - 1) / kBlockSize, tcrc_wal_block{0, 0xffffffffu, 0, 0});
+  out->records = 0;
+  if (n == 0) return Status::OK();
+  Status s = verifier->ScanBlocks(img, n, log_number, out->blocks.data());
+  if (s.ok())
+    for (const tcrc_wal_block& b : out->blocks) out->records += b.n_records;
+  return s;
+}
+
+}  // namespace log
+}  // namespace terarkdb_amd

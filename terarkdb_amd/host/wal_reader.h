@@ -1,0 +1,94 @@
+// Log reader with the call surface of the reference's log::Reader (db/log_reader.h:35-150):
+// ReadRecord(Slice*, std::string*, WALRecoveryMode) -> bool, Reporter::Corruption(bytes,
+// status), UnmarkEOF(), IsEOF(), LastRecordOffset().  It returns the same records and
+// reports the same drops as the reference for the same bytes.
+//
+// The reader parses and reassembles on the host, but it never computes a checksum: the
+// verdict for a physical record comes from the engine, either from a VerifiedLogImage
+// (the whole file checked in one device pass - the recovery case) or, for bytes that
+// image does not cover, from a RecordVerifier call on the block just read.
+#pragma once
+#include <memory>
+#include <string>
+
+#include "files.h"
+#include "wal_format.h"
+
+namespace terarkdb_amd {
+namespace log {
+
+class Reader {
+ public:
+  class Reporter {
+   public:
+    virtual ~Reporter() {}
+    // "bytes" is the approximate number of bytes dropped due to the corruption.
+    virtual void Corruption(size_t bytes, const Status& status) = 0;
+  };
+
+  // `reporter` may be null.  With checksum == false no verdicts are requested.  `verifier`
+  // must outlive the reader (it may be null only when checksum is false or an image that
+  // covers everything read is attached).
+  Reader(std::unique_ptr<SequentialFile>&& file, Reporter* reporter, bool checksum, uint64_t log_num,
+         bool retry_after_eof, RecordVerifier* verifier);
+  ~Reader();
+
+  // Verdicts computed ahead for the first image->size bytes of the file.
+  void AttachVerifiedImage(std::shared_ptr<const VerifiedLogImage> image) { image_ = std::move(image); }
+
+  bool ReadRecord(Slice* record, std::string* scratch,
+                  WALRecoveryMode wal_recovery_mode = WALRecoveryMode::kTolerateCorruptedTailRecords);
+  uint64_t LastRecordOffset() const { return last_record_offset_; }
+  bool IsEOF() const { return eof_; }
+  void UnmarkEOF();
+  SequentialFile* file() { return file_.get(); }
+  // How many times the verifier had to be asked (0 when an attached image covered the file).
+  uint64_t verifier_calls() const { return verifier_calls_; }
+
+ private:
+  // Outcomes of reading one physical record beyond the record types themselves
+  // (db/log_reader.h:119-134).
+  enum {
+    kEof = kMaxRecordType + 1,
+    kBadRecord = kMaxRecordType + 2,
+    kBadHeader = kMaxRecordType + 3,
+    kOldRecord = kMaxRecordType + 4,
+    kBadRecordLen = kMaxRecordType + 5,
+    kBadRecordChecksum = kMaxRecordType + 6,
+  };
+
+  unsigned int NextPhysical(Slice* payload, size_t* drop_size);
+  bool Refill(size_t* drop_size, int* error);
+  bool ChecksumGood();
+  void BufferChanged(bool new_block);
+  void Drop(size_t bytes, const Status& why);
+  void DropCorrupt(size_t bytes, const char* why) { Drop(bytes, Status::Corruption(why)); }
+
+  const std::unique_ptr<SequentialFile> file_;
+  Reporter* const reporter_;
+  const bool checksum_;
+  char* const backing_store_;
+  Slice buffer_;  // unread part of the current block
+  bool eof_;         // the last read came back short
+  bool read_error_;
+  size_t eof_offset_;  // bytes of the current block present when EOF was hit
+  uint64_t last_record_offset_;
+  uint64_t end_of_buffer_offset_;  // file offset just past buffer_
+  const uint64_t log_number_;
+  bool recycled_;
+  const bool retry_after_eof_;
+
+  // verdict state for the records of buffer_
+  RecordVerifier* const verifier_;
+  std::shared_ptr<const VerifiedLogImage> image_;
+  bool verdict_known_;      // first_bad_ is valid for the records now in buffer_
+  uint32_t first_bad_;      // index within the 32 KiB block of the first record failing its CRC
+  uint32_t next_index_;     // index within the 32 KiB block of the record at the front of buffer_
+  uint64_t verifier_calls_;
+
+  Reader(const Reader&) = delete;
+  void operator=(const Reader&) = delete;
+};
+
+}  // namespace log
+}  // namespace terarkdb_amd

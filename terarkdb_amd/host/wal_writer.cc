@@ -1,0 +1,123 @@
+#include "wal_writer.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+namespace terarkdb_amd {
+namespace log {
+
+char* RecordStamper::AllocStaging(size_t bytes) { return static_cast<char*>(malloc(bytes)); }
+void RecordStamper::FreeStaging(char* p) { free(p); }
+
+Writer::Writer(std::unique_ptr<WritableFile>&& dest, uint64_t log_number, bool recycle_log_files, bool manual_flush,
+               RecordStamper* stamper)
+    : dest_(std::move(dest)),
+      block_offset_(0),
+      log_number_(log_number),
+      recycle_log_files_(recycle_log_files),
+      manual_flush_(manual_flush),
+      stamper_(stamper),
+      stage_(nullptr),
+      stage_size_(0),
+      stage_cap_(0),
+      n_physical_(0),
+      crc_bytes_(0) {}
+
+Writer::~Writer() {
+  WriteBuffer();
+  if (stage_) stamper_->FreeStaging(stage_);
+}
+
+void Writer::Reserve(size_t more) {
+  if (stage_size_ + more <= stage_cap_) return;
+  size_t cap = stage_cap_ ? stage_cap_ : (size_t)1 << 16;
+  while (cap < stage_size_ + more) cap *= 2;
+  char* fresh = stamper_->AllocStaging(cap);
+  if (stage_size_) memcpy(fresh, stage_, stage_size_);
+  if (stage_) stamper_->FreeStaging(stage_);
+  stage_ = fresh;
+  stage_cap_ = cap;
+}
+
+// One physical record: header with a blank checksum, then the payload
+// (layout: db/log_writer.cc:104-142; the CRC covers type, log number and payload, not the length).
+void Writer::Frame(RecordType t, const char* payload, size_t n) {
+  const size_t header_size = t >= kRecyclableFullType ? kRecyclableHeaderSize : kHeaderSize;
+  Reserve(header_size + n);
+  char* h = stage_ + stage_size_;
+  memset(h, 0, 4);
+  h[4] = static_cast<char>(n & 0xff);
+  h[5] = static_cast<char>(n >> 8);
+  h[6] = static_cast<char>(t);
+  if (header_size == (size_t)kRecyclableHeaderSize) EncodeFixed32(h + 7, static_cast<uint32_t>(log_number_));
+  if (n) memcpy(h + header_size, payload, n);
+  tcrc_desc span;
+  span.offset = stage_size_ + 6;
+  span.len = static_cast<uint32_t>(header_size - 6 + n);
+  span.init = 0;
+  spans_.push_back(span);
+  stage_size_ += header_size + n;
+  block_offset_ += header_size + n;
+  n_physical_++;
+  crc_bytes_ += span.len;
+}
+
+// Fragmentation rules of db/log_writer.cc:45-100.
+Status Writer::AddRecord(const Slice& slice) {
+  const char* ptr = slice.data();
+  size_t left = slice.size();
+  const size_t header_size = recycle_log_files_ ? kRecyclableHeaderSize : kHeaderSize;
+  const int base = recycle_log_files_ ? kRecyclableFullType - kFullType : 0;
+  bool first_fragment = true;
+  for (;;) {
+    const size_t room = kBlockSize - block_offset_;
+    if (room < header_size) {
+      // too small for a header: zero-fill the tail of the block and move on
+      if (room > 0) {
+        Reserve(room);
+        memset(stage_ + stage_size_, 0, room);
+        stage_size_ += room;
+      }
+      block_offset_ = 0;
+    }
+    const size_t avail = kBlockSize - block_offset_ - header_size;
+    const size_t take = left < avail ? left : avail;
+    const bool last_fragment = take == left;
+    int t;
+    if (first_fragment) {
+      t = last_fragment ? kFullType : kFirstType;
+    } else {
+      t = last_fragment ? kLastType : kMiddleType;
+    }
+    Frame(static_cast<RecordType>(t + base), ptr, take);
+    ptr += take;
+    left -= take;
+    first_fragment = false;
+    if (left == 0) break;
+  }
+  if (manual_flush_) return Status::OK();
+  return WriteBuffer();
+}
+
+Status Writer::Submit() {
+  if (spans_.empty()) return Status::OK();
+  crcs_.resize(spans_.size());
+  Status s = stamper_->Stamp(stage_, stage_size_, spans_.data(), spans_.size(), crcs_.data());
+  if (!s.ok()) return s;
+  for (size_t i = 0; i < spans_.size(); ++i) EncodeFixed32(stage_ + spans_[i].offset - 6, crcs_[i]);
+  spans_.clear();
+  return Status::OK();
+}
+
+Status Writer::WriteBuffer() {
+  Status s = Submit();
+  if (s.ok() && stage_size_) {
+    s = dest_->Append(Slice(stage_, stage_size_));
+    stage_size_ = 0;
+  }
+  if (s.ok()) s = dest_->Flush();
+  return s;
+}
+
+}  // namespace log
+}  // namespace terarkdb_amd

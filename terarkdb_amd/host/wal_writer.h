@@ -1,0 +1,58 @@
+// Log writer with the call surface of the reference's log::Writer (db/log_writer.h:67-113):
+// AddRecord(Slice) -> Status produces byte-identical files.  The masked CRC of every
+// physical record is not computed on the host: fragments are framed into a staging
+// buffer with the checksum field left blank and stamped by the engine in one batch
+// - per AddRecord call, or per WriteBuffer() call when manual_flush is set (the
+// reference's manual_wal_flush mode, db/log_writer.cc:144-146).
+#pragma once
+#include <memory>
+#include <vector>
+
+#include "files.h"
+#include "wal_format.h"
+
+namespace terarkdb_amd {
+namespace log {
+
+class Writer {
+ public:
+  // `stamper` must outlive the writer.
+  Writer(std::unique_ptr<WritableFile>&& dest, uint64_t log_number, bool recycle_log_files, bool manual_flush,
+         RecordStamper* stamper);
+  ~Writer();
+
+  Status AddRecord(const Slice& slice);
+  // Stamps and hands everything framed so far to the file, then flushes it.
+  Status WriteBuffer();
+
+  WritableFile* file() { return dest_.get(); }
+  uint64_t get_log_number() const { return log_number_; }
+  // Records framed but not yet stamped (only non-zero between calls when manual_flush is set).
+  size_t pending_records() const { return spans_.size(); }
+  // Totals since construction: physical records emitted and bytes covered by their CRCs.
+  uint64_t physical_records() const { return n_physical_; }
+  uint64_t crc_bytes() const { return crc_bytes_; }
+
+ private:
+  void Frame(RecordType t, const char* payload, size_t n);
+  void Reserve(size_t more);
+  Status Submit();
+
+  std::unique_ptr<WritableFile> dest_;
+  size_t block_offset_;  // position inside the current 32 KiB block
+  uint64_t log_number_;
+  bool recycle_log_files_;
+  bool manual_flush_;
+  RecordStamper* stamper_;
+  char* stage_;          // framed bytes awaiting their checksums
+  size_t stage_size_, stage_cap_;
+  std::vector<tcrc_desc> spans_;  // CRC-covered span of every pending record
+  std::vector<uint32_t> crcs_;
+  uint64_t n_physical_, crc_bytes_;
+
+  Writer(const Writer&) = delete;
+  void operator=(const Writer&) = delete;
+};
+
+}  // namespace log
+}  // namespace terarkdb_amd

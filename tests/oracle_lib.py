@@ -36,6 +36,7 @@ def lib():
             "oracle_sink_size": (sz, [vp]),
             "oracle_sink_drop": (None, [vp, sz]),
             "oracle_sink_rewind_for_overwrite": (None, [vp]),
+            "oracle_sink_append_raw": (None, [vp, C.c_char_p, sz]),
             "oracle_wal_writer_new": (vp, [vp, u64, i]),
             "oracle_wal_writer_free": (None, [vp]),
             "oracle_wal_writer_use_hw": (None, [vp, i]),

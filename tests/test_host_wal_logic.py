@@ -1,0 +1,77 @@
+"""Host-side framing / reassembly / recovery-policy logic of the engine's log::Writer and
+log::Reader on a machine without a GPU: the two checksum seams are served by callbacks
+into the CPU oracle (tests/engine_log.py), everything else is the shipped C++ code."""
+import json
+import os
+
+import pytest
+
+import oracle_lib as O
+import wal_scenarios as W
+from engine_log import EngineLog
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CAP = json.load(open(os.path.join(HERE, "golden", "reference_captured.json")))
+
+
+def mk(recycle, **kw):
+    return EngineLog(recycle=recycle, ctx=None, **kw)
+
+
+def mk_bulk(recycle, **kw):
+    return EngineLog(recycle=recycle, ctx=None, bulk_image=True, **kw)
+
+
+@pytest.mark.parametrize("recycle", [0, 2])
+@pytest.mark.parametrize("scenario", W.ALL, ids=lambda f: f.__name__)
+def test_log_scenarios(scenario, recycle):
+    scenario(mk, recycle)
+
+
+@pytest.mark.parametrize("recycle", [0, 2])
+@pytest.mark.parametrize("scenario", W.ALL, ids=lambda f: f.__name__)
+def test_log_scenarios_with_whole_file_verdicts(scenario, recycle):
+    """Same cases with the file verified in one pass at the first read (the recovery shape);
+    bytes that arrive later fall back to block-by-block requests."""
+    scenario(mk_bulk, recycle)
+
+
+@pytest.mark.parametrize("recycle", [0, 2])
+def test_many_blocks(recycle):
+    W.many_blocks(mk_bulk, recycle, n=20000)
+
+
+@pytest.mark.parametrize("recycle", [0, 2])
+@pytest.mark.parametrize("manual_flush", [False, True])
+def test_writer_bytes_equal_the_oracle_writers(recycle, manual_flush):
+    a = O.OracleLog(recycle=recycle)
+    b = EngineLog(recycle=recycle, ctx=None, manual_flush=manual_flush)
+    rnd = O.Random(301)
+    for i in range(300):
+        s = W.random_skewed_string(i, rnd)
+        a.write(s)
+        b.write(s)
+    if manual_flush:
+        assert b.written_bytes() == 0  # nothing reaches the file before WriteBuffer()
+        b.flush()
+    assert a.contents() == b.contents()
+
+
+@pytest.mark.parametrize("kind", ["legacy", "recyclable"])
+def test_captured_small_wal_bytes(kind):
+    cap = CAP["wal_small"]
+    t = EngineLog(recycle=(kind == "recyclable"), log_number=cap["log_number"], ctx=None)
+    for r in cap["records"]:
+        t.write(b"a" * 40000 if r == "a*40000" else r.encode())
+    img = t.contents()
+    assert len(img) == cap[kind]["file_size"]
+    assert img[:32].hex() == cap[kind]["first32_hex"]
+
+
+@pytest.mark.parametrize("recycle", [0, 2])
+def test_random_read_whole_file_verdicts_need_no_block_requests(recycle):
+    t = W.random_read(mk_bulk, recycle)
+    assert t.verifier_calls() == 0
+    cap = CAP["wal_random_read"]["recyclable" if recycle else "legacy"]
+    assert t.written_bytes() == cap["file_size"]
+    assert O.value(t.contents()) == int(cap["value_of_whole_file"], 16)
