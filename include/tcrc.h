@@ -95,6 +95,17 @@ int tcrc_dev_batch_verify(tcrc_ctx* ctx, const void* d_base, const tcrc_desc* d_
                           const uint8_t* d_suffix, uint32_t flags, const uint32_t* d_expected, uint32_t* d_out,
                           uint8_t* d_ok, uint64_t* d_counts, void* stream);
 
+/* ---- long buffers ------------------------------------------------------------------ */
+/* d_out[i] = Extend(h_desc[i].init, d_base + h_desc[i].offset, h_desc[i].len) for buffers of
+ * hundreds of KiB up to 1 GiB each: every buffer is cut into segments of segment_len bytes
+ * (0 = choose; otherwise a power of two >= 256) that are checksummed in parallel and merged
+ * with a GF(2) shift-and-xor.  Data is on the GPU, the (few) descriptors are on the host.
+ * Values are plain CRCs (apply tcrc_mask on the host if a masked value is wanted).
+ * Stands in for crc32c::Extend on large inputs (util/crc32c.cc:1226-1228; callers such as
+ * utilities/backupable/backupable_db.cc:1434-1449).  Returns with d_out complete. */
+int tcrc_dev_extend_long(tcrc_ctx* ctx, const void* d_base, const tcrc_desc* h_desc, uint64_t n, uint32_t segment_len,
+                         uint32_t* d_out, void* stream);
+
 /* ---- write-ahead-log images ------------------------------------------------------ */
 /* How the structural walk of one 32 KiB log block ended (db/log_reader.cc:314-384). */
 #define TCRC_WAL_END_CLEAN 0          /* records fill the block exactly */

@@ -37,6 +37,7 @@ SIGNATURES = {
     "tcrc_unmask": (_u32, [_u32]),
     "tcrc_dev_counts_reset": (_i, [_vp, _vp, _vp]),
     "tcrc_dev_wal_verify": (_i, [_vp, _vp, _u64, _u64, _vp, _vp, C.POINTER(_u64), _vp]),
+    "tcrc_dev_extend_long": (_i, [_vp, _vp, _vp, _u64, _u32, _vp, _vp]),
     "tcrc_dev_probe_read": (_i, [_vp, _vp, _u64, _vp, _u32, _vp]),
     "tcrc_dev_blocks_stamp": (_i, [_vp, _vp, _u64, _u32, _u64, _u32, _i, _vp, _u32, _vp, _vp]),
     "tcrc_dev_blocks_verify": (_i, [_vp, _vp, _u64, _u32, _u64, _u32, _i, _vp, _u32, _vp, _vp, _vp, _vp, _vp]),
@@ -159,6 +160,14 @@ class Engine:
         check(lib.tcrc_dev_wal_verify(self.ctx, _dp(img), size, log_number, _dp(blocks), _dp(counts), C.byref(n),
                                       self._stream(stream)))
         return n.value
+
+    def extend_long(self, base, offsets, lens, inits, out, segment_len=0, stream=None):
+        """Host descriptor arrays, device data; out is a device int32/uint32 tensor of len(offsets)."""
+        n = len(offsets)
+        arr = (Desc * n)()
+        for i in range(n):
+            arr[i].offset, arr[i].len, arr[i].init = int(offsets[i]), int(lens[i]), int(inits[i])
+        check(lib.tcrc_dev_extend_long(self.ctx, _dp(base), arr, n, segment_len, _dp(out), self._stream(stream)))
 
     def counts_reset(self, counts, stream=None):
         check(lib.tcrc_dev_counts_reset(self.ctx, _dp(counts), self._stream(stream)))

@@ -107,7 +107,9 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p) {
   const int grp = lane / G;
   const uint32_t* A = lds + (lane & 31);
   const uint32_t* aux = lds + kMainDwords;
-  const uint64_t wave = (uint64_t)blockIdx.x * kWavesPerWg + (tid >> 6);
+  // rounds are dealt to workgroups first, then to the waves of a workgroup, so that a small
+  // batch still spreads over all CUs
+  const uint64_t wave = (uint64_t)blockIdx.x + (uint64_t)gridDim.x * (tid >> 6);
   const uint64_t nwaves = (uint64_t)gridDim.x * kWavesPerWg;
   uint64_t n = p.n;
   if (p.n_dev) {
@@ -116,6 +118,7 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p) {
   }
   const uint64_t nrounds = (n + GPW - 1) / GPW;
   const bool wal_items = (p.flags & kFlagWalItems) != 0;
+  const bool segments = (p.flags & kFlagSegments) != 0;
 
   for (uint64_t round = wave; round < nrounds; round += nwaves) {
     const uint64_t buf = round * GPW + grp;
@@ -240,7 +243,20 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p) {
       if (sfx >= 0) r = aux[768u + ((r ^ (uint32_t)sfx) & 0xffu)] ^ (r >> 8);
       const uint32_t crc = ~r;
       const uint32_t masked = ((crc >> 15) | (crc << 17)) + kMaskDelta;
-      if (p.out) p.out[buf] = (p.flags & TCRC_F_MASK) ? masked : crc;
+      if (segments) {
+        // r is the remainder of this segment alone; q whole segments follow it in its buffer, so it
+        // enters the buffer's remainder advanced through q * segment_len bytes.  The final inversion
+        // rides on the last segment (q == 0).
+        const uint32_t q = p.seg_after[buf];
+        uint32_t a = r, b = p.seg_pow[q], prod = 0;
+        for (int i = 31; i >= 0; --i) {
+          prod ^= ((a >> i) & 1u) ? b : 0u;
+          b = (b >> 1) ^ ((b & 1u) ? 0x82f63b78u : 0u);
+        }
+        atomicXor(&p.out[p.seg_owner[buf]], q == 0 ? ~prod : prod);
+      } else if (p.out) {
+        p.out[buf] = (p.flags & TCRC_F_MASK) ? masked : crc;
+      }
       if (p.verify) {
         const bool good = stored == masked;
         if (p.ok) p.ok[buf] = good ? 1 : 0;
@@ -299,7 +315,7 @@ int launch_batch(tcrc_ctx* ctx, BatchParams p, hipStream_t s) {
   p.tab_main = ctx->d_tab_main[gi];
   p.tab_aux = ctx->d_tab_aux[gi];
   const uint64_t rounds = (p.n + (64 / G) - 1) / (64 / G);
-  uint64_t wgs = (rounds + kWavesPerWg - 1) / kWavesPerWg;
+  uint64_t wgs = rounds;
   if (wgs > (uint64_t)ctx->cus) wgs = (uint64_t)ctx->cus;
   if (wgs == 0) wgs = 1;
   if (ctx->nontemporal)
@@ -425,7 +441,8 @@ int tcrc_shutdown(tcrc_ctx* ctx) {
     if (ctx->d_tab_aux[gi]) (void)hipFree(ctx->d_tab_aux[gi]);
   }
   for (tcrc_scratch* s : {&ctx->wal_counts, &ctx->wal_first, &ctx->wal_items, &ctx->wal_item_block, &ctx->wal_misc,
-                          &ctx->host_data, &ctx->host_desc, &ctx->host_out, &ctx->host_aux, &ctx->host_blocks})
+                          &ctx->host_data, &ctx->host_desc, &ctx->host_out, &ctx->host_aux, &ctx->host_blocks,
+                          &ctx->long_in, &ctx->long_desc, &ctx->long_owner, &ctx->long_after, &ctx->long_pow})
     scratch_release(s);
   if (ctx->host_stream) (void)hipStreamDestroy(ctx->host_stream);
   delete ctx;

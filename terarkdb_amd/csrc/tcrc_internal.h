@@ -12,6 +12,7 @@ namespace tcrc_internal {
 
 // internal flag bits (above the public TCRC_F_* ones)
 constexpr uint32_t kFlagWalItems = 0x100u;  // descriptors are log records: desc.init = index inside the 32 KiB block
+constexpr uint32_t kFlagSegments = 0x200u;  // descriptors are segments of longer buffers: results are shifted and XORed
 
 struct BatchParams {
   const uint8_t* base;
@@ -31,6 +32,9 @@ struct BatchParams {
   const unsigned long long* n_dev;  // when set, the batch size is read from device memory (<= n)
   const uint32_t* item_block;       // kFlagWalItems: 32 KiB block index of every item
   tcrc_wal_block* wal_blocks;       // kFlagWalItems: per block result (first_bad is lowered on a mismatch)
+  const uint32_t* seg_owner;        // kFlagSegments: output slot (buffer index) of every segment
+  const uint32_t* seg_after;        // kFlagSegments: number of whole segments that follow it in its buffer
+  const uint32_t* seg_pow;          // kFlagSegments: seg_pow[q] = x^(8 * segment_len * q) mod P
   const uint32_t* tab_main;  // 1024 dwords: Z_D set
   const uint32_t* tab_aux;   // (1+log2 G) sets of 1024 dwords: Z_4, Z_16, Z_32, ...
 };
@@ -71,6 +75,10 @@ struct tcrc_ctx {
   std::mutex host_mu;
   hipStream_t host_stream = nullptr;
   tcrc_scratch host_data, host_desc, host_out, host_aux, host_blocks;
+  // long-buffer scratch (tcrc_long.hip), guarded by host_mu
+  tcrc_scratch long_in, long_desc, long_owner, long_after, long_pow;
+  uint32_t long_pow_seg = 0;      // segment length the cached power table was built for
+  uint32_t long_pow_count = 0;    // entries in it
 };
 
 namespace tcrc_internal {
