@@ -70,7 +70,7 @@ def cpu_baseline(seconds_budget=12.0):
     t1 = run(1, 2)
     single = 2 * sample_blocks * (BLOCK_LEN + 1) / t1 / 1e9
     passes = max(2, int(seconds_budget * 0.6 / max(t1 / 2 / cores, 1e-3) / 1.0))
-    passes = min(passes, 200)
+    passes = min(passes, 600)
     tn = run(cores, passes)
     multi = passes * (sample_blocks // cores) * cores * (BLOCK_LEN + 1) / tn / 1e9
     return {
@@ -144,9 +144,9 @@ def main():
     for _ in range(args.warmup):
         step()
     # touch every other op of the timed region once, so no first-use set-up cost lands inside it
-    warm = counts[[capi.CNT_MISMATCH, capi.CNT_CHECKED]].clone()
-    if dist:
-        dist.all_reduce(warm)
+    from terarkdb_amd.sharding import allreduce_totals
+    _ = counts.cpu()
+    allreduce_totals(0, 0, None, 0, device="cuda" if dist else None)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     e1.record()
@@ -163,9 +163,12 @@ def main():
     for _ in range(args.steps):
         step()
     ev_end.record()
-    totals = counts[[capi.CNT_MISMATCH, capi.CNT_CHECKED]].clone()
-    if dist:
-        dist.all_reduce(totals)  # the path's only collective: 16 bytes over RCCL
+    c = counts.cpu().numpy().view(np.uint64)  # waits for the K launches
+    fb_local = int(c[capi.CNT_FIRST_BAD])
+    # the path's only exchange: {mismatches, checked} summed and the first bad block min-ed over ranks (RCCL)
+    totals = allreduce_totals(int(c[capi.CNT_MISMATCH]), int(c[capi.CNT_CHECKED]),
+                              None if fb_local == 2**64 - 1 else fb_local, rank * N_BLOCKS,
+                              device="cuda" if dist else None)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -176,12 +179,12 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    mism, checked = int(totals[0].item()), int(totals[1].item())
-    first_bad = int(counts.cpu().numpy().view(np.uint64)[capi.CNT_FIRST_BAD])
+    mism, checked = totals.mismatches, totals.checked
     if mism != N_CORRUPT * args.steps * world or checked != N_BLOCKS * args.steps * world:
         raise SystemExit(f"verification miscounted: {mism} mismatches / {checked} checked")
-    if first_bad != int(bad_blocks[0]):
-        raise SystemExit(f"first bad block {first_bad} != {int(bad_blocks[0])}")
+    want_first = int(np.sort(np.random.default_rng(1000).choice(N_BLOCKS, N_CORRUPT, replace=False))[0])
+    if totals.first_bad != want_first:
+        raise SystemExit(f"first bad block {totals.first_bad} != {want_first}")
 
     avg_ms = ev_start.elapsed_time(ev_end) / args.steps  # average launch duration over the timed region
     alg_bytes = N_BLOCKS * (BLOCK_LEN + 1)  # bytes covered by the CRC: block + type byte

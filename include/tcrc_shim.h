@@ -41,6 +41,8 @@ void* tcrc_shim_wal_writer_new_cb(tcrc_shim_stamp_fn fn, void* user, void* memfi
                                   int manual_flush, int overwrite);
 void* tcrc_shim_wal_writer_open(tcrc_ctx* ctx, const char* path, uint64_t log_number, int recycle, int manual_flush);
 int tcrc_shim_wal_writer_add_record(void* w, const void* data, size_t n);
+/* AddRecord for n records of record_len bytes laid out back to back at base */
+int tcrc_shim_wal_writer_add_records_fixed(void* w, const void* base, size_t record_len, size_t n);
 int tcrc_shim_wal_writer_write_buffer(void* w);
 const char* tcrc_shim_wal_writer_status(void* w);
 uint64_t tcrc_shim_wal_writer_physical_records(void* w);

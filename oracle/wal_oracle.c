@@ -643,3 +643,46 @@ void oracle_wal_scan_blocks(const uint8_t* img, size_t n, uint64_t log_number, u
     out[4 * b + 3] = code;
   }
 }
+
+/* The log of the CPU-reference configuration: n logical records, each a write batch of one
+ * Put (db/write_batch.cc:10-34: fixed64 sequence, fixed32 count = 1, tag kTypeValue = 1,
+ * varint32 key length + key, varint32 value length + value) with a 24-byte key (first 8
+ * bytes the little-endian record index, rest 'k') and a 2000-byte value drawn from
+ * Random(301).Uniform(256): 12 + 1 + 1 + 24 + 2 + 2000 = 2040 bytes per record.
+ * Appends them to the writer; returns the number of logical records written. */
+size_t oracle_wal_write_dbbench_records(void* writer, size_t n, uint32_t seed) {
+  oracle_random rnd;
+  oracle_random_seed(&rnd, seed);
+  uint8_t rec[2040];
+  for (size_t i = 0; i < n; i++) {
+    uint8_t* p = rec;
+    uint64_t seq = i + 1;
+    memcpy(p, &seq, 8); p += 8;
+    put_le32(p, 1); p += 4;
+    *p++ = 1;            /* kTypeValue */
+    *p++ = 24;           /* varint32(24) */
+    uint64_t idx = i;
+    memcpy(p, &idx, 8);
+    memset(p + 8, 'k', 16);
+    p += 24;
+    *p++ = 0xd0;         /* varint32(2000) = d0 0f */
+    *p++ = 0x0f;
+    for (int k = 0; k < 2000; k++) p[k] = (uint8_t)oracle_random_uniform(&rnd, 256);
+    oracle_wal_writer_add_record(writer, rec, sizeof(rec));
+  }
+  return n;
+}
+
+/* Reads every record of the reader to the end; returns the number of logical records and adds up
+ * their sizes (the timed CPU read-back of the reference configuration). */
+size_t oracle_wal_read_all(void* reader, int mode, uint64_t* bytes_out) {
+  const uint8_t* rec;
+  size_t n, count = 0;
+  uint64_t bytes = 0;
+  while (oracle_wal_reader_read_record(reader, mode, &rec, &n)) {
+    count++;
+    bytes += n;
+  }
+  if (bytes_out) *bytes_out = bytes;
+  return count;
+}

@@ -64,6 +64,7 @@ SIGNATURES.update({
     "tcrc_shim_wal_writer_new_cb": (_vp, [STAMP_FN, _vp, _vp, _u64, _i, _i, _i]),
     "tcrc_shim_wal_writer_open": (_vp, [_vp, C.c_char_p, _u64, _i, _i]),
     "tcrc_shim_wal_writer_add_record": (_i, [_vp, _vp, _sz]),
+    "tcrc_shim_wal_writer_add_records_fixed": (_i, [_vp, _vp, _sz, _sz]),
     "tcrc_shim_wal_writer_write_buffer": (_i, [_vp]),
     "tcrc_shim_wal_writer_status": (C.c_char_p, [_vp]),
     "tcrc_shim_wal_writer_physical_records": (_u64, [_vp]),

@@ -73,23 +73,6 @@ __device__ __forceinline__ uint32_t fold_aux(const uint32_t* t, uint32_t c) {
   return t[c & 0xffu] ^ t[256u + ((c >> 8) & 0xffu)] ^ t[512u + ((c >> 16) & 0xffu)] ^ t[768u + (c >> 24)];
 }
 
-// The 16-byte column that starts m bytes into the message with -16 < m < 0: the
-// bytes before the message are zeros; the initial register r0 is XORed into
-// message bytes 0..3.
-__device__ __noinline__ uint4 load_straddle(const uint8_t* ptr, int m, uint32_t r0) {
-  uint32_t d[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    const int mo = m + k;
-    if (mo >= 0) {
-      uint32_t b = ptr[mo];
-      if (mo < 4) b ^= (r0 >> (8 * mo)) & 0xffu;
-      d[k >> 2] |= b << (8 * (k & 3));
-    }
-  }
-  return make_uint4(d[0], d[1], d[2], d[3]);
-}
-
 template <int G, bool NT>
 __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p) {
   constexpr int D = 16 * G;
@@ -148,11 +131,11 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p) {
         stored = p.expected[buf];
       } else {
         const uint8_t* e = (p.flags & TCRC_F_EXPECT_AFTER) ? p.base + off + len : p.base + off - 6;
-        stored = (uint32_t)e[0] | ((uint32_t)e[1] << 8) | ((uint32_t)e[2] << 16) | ((uint32_t)e[3] << 24);
+        __builtin_memcpy(&stored, e, 4);  // one unaligned dword load
       }
     }
     const uint32_t r0 = ~init;
-    const bool live = valid && len >= 4;  // shorter messages take the byte path at the end
+    const bool live = valid && len >= 16;  // shorter messages take the byte path at the end
     const uint32_t elen = live ? len : 0u;
     const uint32_t R = (elen + D - 1) / D;
     uint32_t Rmax = R;
@@ -161,61 +144,87 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p) {
       const uint32_t other = __shfl_xor(Rmax, o);
       Rmax = other > Rmax ? other : Rmax;
     }
+    // Rows are handled four at a time; the count is rounded up with empty leading rows.
+    const uint32_t groups4 = (Rmax + 3u) >> 2;
     const uint8_t* ptr = p.base + off;
-    // message offset of this lane's column in row `it`: m0 + it*D
-    int m = (int)elen + 16 * j - (int)(Rmax * D);
-    uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-    uint32_t it = 0;
-    const bool all_live = __all(live);
-
-#define TCRC_ROW(V_)                  \
-  do {                                \
-    s0 = fold_main(A, s0) ^ (V_).x;   \
-    s1 = fold_main(A, s1) ^ (V_).y;   \
-    s2 = fold_main(A, s2) ^ (V_).z;   \
-    s3 = fold_main(A, s3) ^ (V_).w;   \
-  } while (0)
-
-    // Rows in which some lane's column is not a plain full load.
-    while (it < Rmax) {
-      if (all_live && !__any(m < 4)) break;
-      uint4 w = make_uint4(0u, 0u, 0u, 0u);
-      if (live) {
-        if (m >= 0) {
-          w = load16<NT>(ptr + m);
-          if (m < 4) w.x ^= r0 >> (8 * m);
-        } else if (m > -16) {
-          w = load_straddle(ptr, m, r0);
+    // Message offset of this lane's column in row r is m0 + r*D.  Rows are laid out so that every
+    // buffer of the wave ends with the last row; a column with m <= -16 lies wholly before its
+    // message (zeros), -16 < m < 0 straddles the start, 0 <= m < 4 holds part of the first four
+    // message bytes (which carry the initial register).
+    const int m0 = (int)elen + 16 * j - (int)(groups4 * 4u * D);
+    int row_straddle = -1, row_init = -1;
+    uint4 w_straddle = make_uint4(0u, 0u, 0u, 0u);
+    if (live) {
+      if (m0 >= 0) {
+        if (m0 < 4) row_init = 0;
+      } else {
+        const uint32_t a = (uint32_t)(-m0);
+        const uint32_t r = a / D, rem = a - r * D;  // m at row r is -rem
+        if (rem == 0) {
+          row_init = (int)r;
+        } else if (rem < 16) {
+          row_straddle = (int)r;
+          // message bytes 0..15 (len >= 16) with the initial register folded in, moved up by rem bytes
+          const uint4 v = load16<false>(ptr);
+          unsigned long long lo = ((unsigned long long)v.y << 32) | (v.x ^ r0);
+          unsigned long long hi = ((unsigned long long)v.w << 32) | v.z;
+          const uint32_t sh = 8u * rem;
+          if (sh >= 64u) {
+            hi = lo << (sh - 64u);
+            lo = 0;
+          } else {
+            hi = (hi << sh) | (lo >> (64u - sh));
+            lo <<= sh;
+          }
+          w_straddle = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+        } else if (D - rem < 4) {
+          row_init = (int)r + 1;
         }
       }
-      TCRC_ROW(w);
-      m += D;
-      ++it;
     }
-    // Steady state: every lane loads a full column.
-    if (it < Rmax) {
-      const uint8_t* q = ptr + m;
-      uint32_t left = Rmax - it;
-      while (left >= 4) {
+    uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+
+    // Rows go in bursts of four: four 16-byte loads per lane are issued back to back (512
+    // contiguous bytes per buffer), then folded in order as they arrive.  Bursts without overlap
+    // inside a wave measured faster than keeping loads in flight across the folds; the other
+    // waves of the CU cover the latency.  Message offsets only grow with g, so once a whole wave
+    // is past its message starts it stays on the short path.
+    auto fold_plain = [&](const uint4& v) {
+      s0 = fold_main(A, s0) ^ v.x;
+      s1 = fold_main(A, s1) ^ v.y;
+      s2 = fold_main(A, s2) ^ v.z;
+      s3 = fold_main(A, s3) ^ v.w;
+    };
+    // A row that may lie (partly) before the message start or carry the initial register.
+    auto fold_checked = [&](uint32_t r) {
+      const int m = m0 + (int)(r * D);
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (live && m >= 0) v = load16<NT>(ptr + m);
+      if ((int)r == row_straddle) v = w_straddle;
+      if ((int)r == row_init) v.x ^= r0 >> (8 * m);
+      fold_plain(v);
+    };
+    bool wave_regular = false;  // every lane: live and m >= 4 from this group on
+    for (uint32_t g = 0; g < groups4; ++g) {
+      const int mg = m0 + (int)(g * 4u * D);
+      if (!wave_regular) wave_regular = __all(live && mg >= 4);
+      if (wave_regular) {
+        const uint8_t* q = ptr + mg;
         const uint4 a = load16<NT>(q);
         const uint4 b = load16<NT>(q + D);
         const uint4 c = load16<NT>(q + 2 * D);
         const uint4 d = load16<NT>(q + 3 * D);
-        q += 4 * D;
-        TCRC_ROW(a);
-        TCRC_ROW(b);
-        TCRC_ROW(c);
-        TCRC_ROW(d);
-        left -= 4;
-      }
-      while (left) {
-        const uint4 a = load16<NT>(q);
-        q += D;
-        TCRC_ROW(a);
-        --left;
+        fold_plain(a);
+        fold_plain(b);
+        fold_plain(c);
+        fold_plain(d);
+      } else {
+        fold_checked(4u * g);
+        fold_checked(4u * g + 1u);
+        fold_checked(4u * g + 2u);
+        fold_checked(4u * g + 3u);
       }
     }
-#undef TCRC_ROW
 
     // Column states -> one value per lane (bytes j*16 .. j*16+15 of the last row).
     uint32_t u = fold_aux(aux, s0) ^ s1;

@@ -128,6 +128,18 @@ int tcrc_shim_wal_writer_add_record(void* w, const void* data, size_t n) {
   b->last_status = s.ToString();
   return s.ok() ? 0 : -1;
 }
+int tcrc_shim_wal_writer_add_records_fixed(void* w, const void* base, size_t record_len, size_t n) {
+  WriterBox* b = static_cast<WriterBox*>(w);
+  const char* p = static_cast<const char*>(base);
+  for (size_t i = 0; i < n; ++i) {
+    Status s = b->writer->AddRecord(Slice(p + i * record_len, record_len));
+    if (!s.ok()) {
+      b->last_status = s.ToString();
+      return -1;
+    }
+  }
+  return 0;
+}
 int tcrc_shim_wal_writer_write_buffer(void* w) {
   WriterBox* b = static_cast<WriterBox*>(w);
   Status s = b->writer->WriteBuffer();

@@ -63,6 +63,8 @@ def lib():
             "oracle_wal_reader_read_record": (i, [vp, i, C.POINTER(vp), C.POINTER(sz)]),
             "oracle_wal_list_physical": (sz, [vp, sz, u64, vp, sz]),
             "oracle_wal_scan_blocks": (None, [vp, sz, u64, vp]),
+            "oracle_wal_write_dbbench_records": (sz, [vp, sz, u32]),
+            "oracle_wal_read_all": (sz, [vp, i, C.POINTER(u64)]),
         }
         for name, (res, args) in sig.items():
             f = getattr(L, name)

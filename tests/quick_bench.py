@@ -32,7 +32,8 @@ def main():
     scratch = torch.zeros(2 * 1024 * 256, dtype=torch.int32, device="cuda")
     lanes_list = [int(x) for x in os.environ.get("QB_LANES", "8,16").split(",")]
     for rep in range(2):
-        for nt in ("0", "1"):
+      for rmap in ("0",):
+        for nt in ("1",):
             os.environ["TCRC_NONTEMPORAL"] = nt
             e = G.engine(8)
             for wpc in (1, 2):

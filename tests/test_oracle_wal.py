@@ -82,3 +82,31 @@ def test_hw_variant_writes_identical_bytes():
         assert x == y
         if x == "EOF":
             break
+
+
+def test_dbbench_shape_log_facts_scaled():
+    """The CPU-reference configuration at 1/20 scale: same record shape, and the captured
+    full-size facts follow from the same geometry (16 records per 32 KiB block, one split per block)."""
+    import ctypes as C
+    cap = CAP["wal_db_bench_shape"]
+    t = mk(0, log_number=7)
+    n = 50000
+    O.lib().oracle_wal_write_dbbench_records(t.writer, n, 301)
+    phys = O.lib().oracle_wal_writer_physical_records(t.writer)
+    crc_bytes = O.lib().oracle_wal_writer_crc_bytes(t.writer)
+    size = t.written_bytes()
+    # the file is n * 2040 payload bytes + 7 per physical record + the zero trailers of blocks that end
+    # with fewer than 7 free bytes
+    pad = size - (n * cap["record_size"] + 7 * phys)
+    assert 0 <= pad < 7 * (size // 32768 + 1)
+    assert crc_bytes == n * cap["record_size"] + phys
+    # the same two relations pin the captured full-size numbers
+    cap_pad = cap["file_size"] - (cap["logical_records"] * cap["record_size"] + 7 * cap["physical_records"])
+    assert 0 <= cap_pad < 7 * (cap["file_size"] // 32768 + 1)
+    assert cap["crc_covered_bytes"] == cap["logical_records"] * cap["record_size"] + cap["physical_records"]
+    assert cap["full"] + cap["first"] + cap["last"] == cap["physical_records"]
+    # ratio of split records matches: one FIRST/LAST pair per 32 KiB block
+    assert abs((phys - n) / n - cap["first"] / cap["logical_records"]) < 1e-3
+    total = C.c_uint64()
+    assert O.lib().oracle_wal_read_all(t.reader, 0, C.byref(total)) == n
+    assert total.value == n * cap["record_size"]

@@ -1,0 +1,262 @@
+#!/usr/bin/env python3
+"""Measures the configurations other than the headline one on a GPU box and writes one JSON
+document (kept under profiles/): the CPU-reference log configuration, device-resident and
+host-inclusive log verification, host-inclusive block stamping, the mixed-size log, and long
+buffers.  GB/s = CRC-covered bytes / time, 1 GB = 1e9 B.
+
+usage: python tools/measure_paths.py [out.json]
+"""
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import gpu_util as G  # noqa: E402
+import oracle_lib as O  # noqa: E402
+import terarkdb_amd.capi as capi  # noqa: E402
+
+L = capi.lib
+OL = O.lib()
+
+
+def wall(fn, reps=3):
+    best = None
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return best
+
+
+def dev_time(fn, iters=10, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e-3
+
+
+def pinned_copy(eng, arr):
+    p = L.tcrc_host_alloc(eng.ctx, arr.size)
+    C.memmove(p, arr.ctypes.data, arr.size)
+    return p
+
+
+def main():
+    out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "paths.json")
+    eng = capi.Engine(0)
+    res = {"device": eng.describe(), "host_cpus_used": 1}
+
+    # ---- config 1: CPU reference, 1M db_bench-shaped records through the log writer/reader ----------
+    n_rec = int(os.environ.get("MP_RECORDS", "1000000"))
+    t = O.OracleLog(recycle=False, log_number=7, hw=True)
+    t0 = time.perf_counter()
+    OL.oracle_wal_write_dbbench_records(t.writer, n_rec, 301)
+    t_write = time.perf_counter() - t0
+    size = t.written_bytes()
+    phys = OL.oracle_wal_writer_physical_records(t.writer)
+    crc_bytes = OL.oracle_wal_writer_crc_bytes(t.writer)
+    total = C.c_uint64()
+    t0 = time.perf_counter()
+    got = OL.oracle_wal_read_all(t.reader, 0, C.byref(total))
+    t_read = time.perf_counter() - t0
+    assert got == n_rec
+    img = np.frombuffer((C.c_uint8 * size).from_address(OL.oracle_sink_data(t.sink)), dtype=np.uint8)
+    blocks_cpu = np.zeros(((size + 32767) // 32768, 4), dtype=np.uint32)
+    t0 = time.perf_counter()
+    OL.oracle_wal_scan_blocks(img.ctypes.data, size, 7, blocks_cpu.ctypes.data)  # table path, one thread
+    t_scan_table = time.perf_counter() - t0
+    res["config1_cpu_reference"] = {
+        "logical_records": n_rec, "physical_records": int(phys), "file_bytes": int(size),
+        "crc_covered_bytes": int(crc_bytes),
+        "writer_seconds": round(t_write, 3), "writer_GBps": round(crc_bytes / t_write / 1e9, 2),
+        "writer_note": "includes generating the 2000-byte values with the reference's Random",
+        "reader_seconds": round(t_read, 3), "reader_GBps": round(crc_bytes / t_read / 1e9, 2),
+        "kind": "oracle port, SSE4.2+PCLMUL path, 1 thread",
+    }
+    if n_rec == 1000000:
+        assert (int(phys), int(size), int(crc_bytes)) == (1062207, 2047436274, 2041062207), (phys, size, crc_bytes)
+        res["config1_cpu_reference"]["matches_captured_reference_facts"] = True
+
+    # ---- config 1 on the device: verify the same image ------------------------------------------------
+    dev = torch.from_numpy(img.copy()).cuda()
+    nb = (size + 32767) // 32768
+    dblocks = torch.zeros((nb, 4), dtype=torch.int32, device="cuda")
+    counts = torch.zeros(3, dtype=torch.int64, device="cuda")
+
+    def dv():
+        eng.counts_reset(counts)
+        return eng.wal_verify(dev, size, 7, dblocks, counts)
+
+    nrec_dev = dv()
+    torch.cuda.synchronize()
+    assert nrec_dev == phys
+    assert (dblocks.cpu().numpy().view(np.uint32) == blocks_cpu).all()
+    t_dev = wall(dv, reps=5)
+    res["config1_device_log_verify"] = {
+        "seconds": round(t_dev, 6), "GBps": round(crc_bytes / t_dev / 1e9, 1),
+        "pct_hbm_peak": round(100 * crc_bytes / t_dev / 8e12, 1),
+        "note": "walk (count) + scan + walk (emit) + batch CRC, one host round trip per GiB, data resident in HBM",
+    }
+    hblocks = np.zeros((nb, 4), dtype=np.uint32)
+    hcounts = np.zeros(3, dtype=np.uint64)
+
+    def hv(ptr):
+        rc = L.tcrc_host_wal_verify(eng.ctx, ptr, size, 7, hblocks.ctypes.data, hcounts.ctypes.data, None)
+        assert rc == 0
+
+    t_pageable = wall(lambda: hv(img.ctypes.data), reps=2)
+    pin = pinned_copy(eng, img)
+    t_pinned = wall(lambda: hv(pin), reps=3)
+    assert (hblocks == blocks_cpu).all()
+    res["config1_host_log_verify"] = {
+        "pageable_GBps": round(crc_bytes / t_pageable / 1e9, 2), "pinned_GBps": round(crc_bytes / t_pinned / 1e9, 2),
+        "note": "host image -> H2D -> device verify -> per-block results D2H",
+    }
+    L.tcrc_host_free(eng.ctx, pin)
+
+    # ---- config 1 through the engine's writer in group-commit mode --------------------------------
+    f = L.tcrc_shim_memfile_new()
+    w = L.tcrc_shim_wal_writer_new(eng.ctx, f, 7, 0, 1, 0)
+    # logical records again, back to back (regenerated the same way through a scratch oracle writer)
+    recs = np.empty(n_rec * 2040, dtype=np.uint8)
+    rnd = O.Random(301)
+    # take the payloads back out of the oracle image instead of regenerating them in Python
+    lst, n_list = O.list_physical(bytes(img[: min(size, 40 * 1024 * 1024)]), 7)
+    sample_records = []
+    cur = b""
+    for off, typ, ln, _ in lst:
+        frag = bytes(img[int(off) + 7: int(off) + 7 + int(ln)])
+        if typ == 1:
+            sample_records.append(frag)
+        elif typ == 2:
+            cur = frag
+        elif typ == 3:
+            cur += frag
+        elif typ == 4:
+            sample_records.append(cur + frag)
+    k = min(len(sample_records), 15000)
+    flat = np.frombuffer(b"".join(sample_records[:k]), dtype=np.uint8)
+    t0 = time.perf_counter()
+    assert L.tcrc_shim_wal_writer_add_records_fixed(w, flat.ctypes.data, 2040, k) == 0
+    assert L.tcrc_shim_wal_writer_write_buffer(w) == 0
+    t_gc = time.perf_counter() - t0
+    wsize = L.tcrc_shim_memfile_size(f)
+    same = C.string_at(L.tcrc_shim_memfile_data(f), wsize) == bytes(img[:wsize])
+    res["config1_engine_writer_group_commit"] = {
+        "records": k, "seconds": round(t_gc, 4), "GBps": round(k * 2040 / t_gc / 1e9, 2),
+        "bytes_identical_to_cpu_writer": bool(same),
+        "note": "AddRecord x k framed on the host into pinned staging, one device submission at WriteBuffer()",
+    }
+    assert same
+    t0 = time.perf_counter()
+    w2 = L.tcrc_shim_wal_writer_new(eng.ctx, L.tcrc_shim_memfile_new(), 7, 0, 0, 0)
+    kk = 2000
+    assert L.tcrc_shim_wal_writer_add_records_fixed(w2, flat.ctypes.data, 2040, kk) == 0
+    t_sync = time.perf_counter() - t0
+    res["config1_engine_writer_per_record"] = {
+        "records": kk, "microseconds_per_record": round(t_sync / kk * 1e6, 1),
+        "note": "manual_flush off: every AddRecord is its own device round trip (latency-bound)",
+    }
+    del dev, dblocks
+    torch.cuda.empty_cache()
+
+    # ---- config 2 with the copies: 1 GiB of 8 KiB blocks from host memory ----------------------------
+    nblk, blen = 131072, 8192
+    host = O.splitmix(nblk * blen, 301)
+    hout = np.zeros(nblk, dtype=np.uint32)
+
+    def hs(ptr):
+        assert L.tcrc_host_blocks_stamp(eng.ctx, ptr, nblk, blen, blen, 0, 0, capi.F_MASK, hout.ctypes.data) == 0
+
+    t_pg = wall(lambda: hs(host.ctypes.data), reps=2)
+    assert int(np.bitwise_xor.reduce(hout)) == 0x0744A84E
+    pin = pinned_copy(eng, host)
+    t_pin = wall(lambda: hs(pin), reps=3)
+    assert int(np.bitwise_xor.reduce(hout)) == 0x0744A84E
+    L.tcrc_host_free(eng.ctx, pin)
+    res["config2_host_inclusive"] = {
+        "pageable_GBps": round(nblk * (blen + 1) / t_pg / 1e9, 2), "pinned_GBps": round(nblk * (blen + 1) / t_pin / 1e9, 2),
+        "note": "H2D of 1 GiB + kernel + D2H of 512 KiB of trailers; bounded by the host link (PCIe Gen5 x16, 63 GB/s spec)",
+    }
+
+    # ---- config 3: mixed-size log, >= 256 MiB, both header kinds, with seeded bit flips ------------
+    for recycle in (0, 1):
+        tl = O.OracleLog(recycle=bool(recycle), log_number=123)
+        rnd = O.Random(301)
+        piece = O.build_wal_image(bool(recycle), n_random=0)  # the edge-case records
+        while tl.written_bytes() < 256 * 1024 * 1024:
+            tl.write(O.big_string(b"%d." % tl.written_bytes(), rnd.skewed(17)))
+        size3 = tl.written_bytes()
+        img3 = np.frombuffer((C.c_uint8 * size3).from_address(OL.oracle_sink_data(tl.sink)), dtype=np.uint8).copy()
+        rng = np.random.default_rng(recycle)
+        for _ in range(1000):
+            img3[int(rng.integers(0, size3))] ^= 1 << int(rng.integers(0, 8))
+        nb3 = (size3 + 32767) // 32768
+        want = np.zeros((nb3, 4), dtype=np.uint32)
+        t0 = time.perf_counter()
+        OL.oracle_wal_scan_blocks(img3.ctypes.data, size3, 123, want.ctypes.data)
+        t_cpu3 = time.perf_counter() - t0
+        d3 = torch.from_numpy(img3).cuda()
+        b3 = torch.zeros((nb3, 4), dtype=torch.int32, device="cuda")
+
+        def v3():
+            eng.counts_reset(counts)
+            eng.wal_verify(d3, size3, 123, b3, counts)
+
+        v3()
+        torch.cuda.synchronize()
+        got = b3.cpu().numpy().view(np.uint32)
+        assert (got == want).all()
+        t3 = wall(v3, reps=5)
+        covered = int(want[:, 2].sum())  # bytes walked, close to the covered bytes
+        res[f"config3_mixed_log_{'recyclable' if recycle else 'legacy'}"] = {
+            "image_bytes": int(size3), "records": int(want[:, 0].sum()),
+            "blocks_with_bad_record": int((want[:, 1] != 0xffffffff).sum()),
+            "identical_to_cpu_reader_rules": True,
+            "device_seconds": round(t3, 6), "device_GBps": round(covered / t3 / 1e9, 1),
+            "cpu_table_path_seconds": round(t_cpu3, 3),
+        }
+        tl.close()
+        del d3, b3
+
+    # ---- config 4: long buffers ----------------------------------------------------------------------
+    S = O.splitmix(64 * 4 * 1024 * 1024, 301)
+    dS = torch.from_numpy(S).cuda()
+    long_res = {}
+    for sz in (256 * 1024, 1024 * 1024, 4 * 1024 * 1024):
+        o1 = torch.zeros(1, dtype=torch.int32, device="cuda")
+        t1 = wall(lambda: eng.extend_long(dS, [0], [sz], [0], o1), reps=20)
+        assert int(o1.cpu().numpy().view(np.uint32)[0]) == O.value(S[:sz], "hw")
+        offs = [i * sz for i in range(64)]
+        o64 = torch.zeros(64, dtype=torch.int32, device="cuda")
+        t64 = wall(lambda: eng.extend_long(dS, offs, [sz] * 64, [0] * 64, o64), reps=20)
+        want = O.batch_extend(S, np.array(offs, np.uint64), np.full(64, sz, np.uint32))
+        assert (o64.cpu().numpy().view(np.uint32) == want).all()
+        long_res[str(sz)] = {"single_us": round(t1 * 1e6, 1), "single_GBps": round(sz / t1 / 1e9, 1),
+                             "batch64_us": round(t64 * 1e6, 1), "batch64_GBps": round(64 * sz / t64 / 1e9, 1)}
+    res["config4_long_buffers"] = long_res
+    res["config4_note"] = "host call to completion (descriptor upload, expand kernel, CRC kernel, sync); device-resident data"
+
+    os.makedirs(os.path.dirname(out_path), exist_ok=True)
+    json.dump(res, open(out_path, "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
