@@ -129,7 +129,7 @@ typedef struct tcrc_wal_block {
  * d_blocks[b] describes block b = bytes [32768*b, 32768*(b+1)) of the image.  Within a
  * block the reference stops at the first bad checksum, so first_bad is what its policy
  * layer needs.  d_counts accumulates TCRC_CNT_* over all candidate records.  Synchronises
- * the stream once per GiB (the record count is needed on the host); on return the rest
+ * the stream once per 8 GiB (the record count is needed on the host); on return the rest
  * of the work is enqueued on `stream`.  *h_records, if not NULL, receives the number of
  * candidate records. */
 int tcrc_dev_wal_verify(tcrc_ctx* ctx, const void* d_img, uint64_t size, uint64_t log_number, tcrc_wal_block* d_blocks,

@@ -10,6 +10,14 @@ if not os.path.exists(LIB_PATH):
         f"{LIB_PATH} is missing: build it with `make -C terarkdb_amd/csrc` (or __graft_entry__.build()). "
         "The engine has no CPU fallback.")
 
+# PyTorch-ROCm wheels ship their own copy of the HIP/HSA runtime.  Two copies in one process
+# cannot both see the GPU, so when torch is around it is loaded first and libtcrc.so then binds
+# to the runtime torch brought (same soname) instead of pulling in /opt/rocm's.
+try:
+    import torch  # noqa: F401
+except ImportError:  # a process without torch just uses the system runtime
+    pass
+
 lib = C.CDLL(LIB_PATH)
 
 OK = 0

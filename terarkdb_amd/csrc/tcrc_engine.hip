@@ -41,6 +41,7 @@ constexpr int kMainDwords = 32768;   // 4 tables x 256 entries x 32 replicas
 constexpr uint32_t kMaskDelta = 0xa282ead8u;
 
 template <int G> struct Geo;
+template <> struct Geo<4>  { static constexpr int kLog2 = 2; };
 template <> struct Geo<8>  { static constexpr int kLog2 = 3; };
 template <> struct Geo<16> { static constexpr int kLog2 = 4; };
 template <> struct Geo<64> { static constexpr int kLog2 = 6; };
@@ -103,14 +104,22 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p) {
   const bool wal_items = (p.flags & kFlagWalItems) != 0;
   const bool segments = (p.flags & kFlagSegments) != 0;
 
+  // the descriptor of the next round is fetched while the current round runs
+  tcrc_desc d_next = {0, 0, 0};
+  if (p.desc && wave < nrounds && wave * GPW + grp < n) d_next = p.desc[wave * GPW + grp];
+
   for (uint64_t round = wave; round < nrounds; round += nwaves) {
     const uint64_t buf = round * GPW + grp;
     const bool valid = buf < n;
     uint64_t off = 0;
     uint32_t len = 0, init = 0, item_index = 0;
+    const tcrc_desc d = d_next;
+    if (p.desc) {
+      const uint64_t nb = (round + nwaves) * GPW + grp;
+      if (round + nwaves < nrounds && nb < n) d_next = p.desc[nb];
+    }
     if (valid) {
       if (p.desc) {
-        const tcrc_desc d = p.desc[buf];
         off = d.offset;
         len = d.len;
         init = d.init;
@@ -309,7 +318,7 @@ __global__ void k_counts_reset(unsigned long long* c) {
   c[TCRC_CNT_CHECKED] = 0ull;
 }
 
-constexpr int kGeoLanes[kGeoCount] = {8, 16, 64};
+constexpr int kGeoLanes[kGeoCount] = {4, 8, 16, 64};
 
 
 int geo_index(int g) {
@@ -376,6 +385,7 @@ int run_batch(tcrc_ctx* ctx, BatchParams p, void* stream) {
   int g = ctx->forced_g;
   if (g == 0) g = 8;
   switch (g) {
+    case 4: return launch_batch<4>(ctx, p, s);
     case 8: return launch_batch<8>(ctx, p, s);
     case 16: return launch_batch<16>(ctx, p, s);
     case 64: return launch_batch<64>(ctx, p, s);
@@ -399,8 +409,10 @@ int tcrc_init(int device, tcrc_ctx** out) {
   if (!out) return fail(TCRC_ERR_INVALID, "null out pointer");
   *out = nullptr;
   int count = 0;
-  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
-    return fail(TCRC_ERR_NO_DEVICE, "no HIP device available: the tcrc engine has no CPU fallback");
+  const hipError_t ce = hipGetDeviceCount(&count);
+  if (ce != hipSuccess || count <= 0)
+    return fail(TCRC_ERR_NO_DEVICE, std::string("no HIP device available (") + hipGetErrorString(ce) +
+                                        "): the tcrc engine has no CPU fallback");
   if (device < 0 || device >= count) return fail(TCRC_ERR_INVALID, "device index out of range");
   HIP_TRY(hipSetDevice(device));
   hipDeviceProp_t prop;

@@ -39,7 +39,7 @@ struct BatchParams {
   const uint32_t* tab_aux;   // (1+log2 G) sets of 1024 dwords: Z_4, Z_16, Z_32, ...
 };
 
-constexpr int kGeoCount = 3;
+constexpr int kGeoCount = 4;
 
 int fail(int code, const std::string& msg);
 
@@ -66,8 +66,8 @@ struct tcrc_ctx {
   int cus = 0;
   int forced_g = 0;
   bool nontemporal = true;  // batch data is read once: keep it from displacing other lines in L2/MALL
-  uint32_t* d_tab_main[tcrc_internal::kGeoCount] = {nullptr, nullptr, nullptr};
-  uint32_t* d_tab_aux[tcrc_internal::kGeoCount] = {nullptr, nullptr, nullptr};
+  uint32_t* d_tab_main[tcrc_internal::kGeoCount] = {};
+  uint32_t* d_tab_aux[tcrc_internal::kGeoCount] = {};
   std::string description;
   // log-scan scratch (tcrc_wal.hip)
   tcrc_scratch wal_counts, wal_first, wal_items, wal_item_block, wal_misc;

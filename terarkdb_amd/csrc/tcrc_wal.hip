@@ -111,32 +111,38 @@ __global__ __launch_bounds__(256) void k_wal_walk(WalkParams p) {
   }
 }
 
-// out[i] = sum(in[0..i)), out[n] = total; one workgroup.
+// out[i] = sum(in[0..i)), out[n] = total; one workgroup of 16 waves.  1024 elements per pass:
+// a shuffle scan inside each wave, the 16 wave totals through LDS, a running carry across passes.
 __global__ __launch_bounds__(1024) void k_scan_counts(const uint32_t* in, uint32_t* out, uint32_t n,
                                                       unsigned long long* total) {
-  __shared__ uint32_t part[1024];
-  const uint32_t t = threadIdx.x;
-  const uint32_t chunk = (n + 1023u) / 1024u;
-  const uint32_t lo = t * chunk < n ? t * chunk : n;
-  const uint32_t hi = lo + chunk < n ? lo + chunk : n;
-  uint32_t s = 0;
-  for (uint32_t i = lo; i < hi; ++i) s += in[i];
-  part[t] = s;
-  __syncthreads();
-  for (uint32_t d = 1; d < 1024u; d <<= 1) {
-    const uint32_t v = t >= d ? part[t - d] : 0u;
+  __shared__ uint32_t wave_sum[16];
+  const uint32_t t = threadIdx.x, lane = t & 63u, w = t >> 6;
+  uint32_t carry = 0;
+  for (uint32_t base = 0; base < n; base += 1024u) {
+    const uint32_t i = base + t;
+    const uint32_t v = i < n ? in[i] : 0u;
+    uint32_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t up = __shfl_up(incl, d);
+      if ((int)lane >= d) incl += up;
+    }
+    if (lane == 63u) wave_sum[w] = incl;
     __syncthreads();
-    part[t] += v;
+    uint32_t before = 0, all = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 16u; ++k) {
+      const uint32_t sk = wave_sum[k];
+      before += k < w ? sk : 0u;
+      all += sk;
+    }
+    if (i < n) out[i] = carry + before + incl - v;
+    carry += all;
     __syncthreads();
   }
-  uint32_t run = part[t] - s;  // exclusive prefix of this thread's chunk
-  for (uint32_t i = lo; i < hi; ++i) {
-    out[i] = run;
-    run += in[i];
-  }
-  if (t == 1023u) {
-    out[n] = part[1023];
-    *total = part[1023];
+  if (t == 0) {
+    out[n] = carry;
+    *total = carry;
   }
 }
 
@@ -152,9 +158,9 @@ extern "C" int tcrc_dev_wal_verify(tcrc_ctx* ctx, const void* d_img, uint64_t si
   HIP_TRY(hipSetDevice(ctx->device));
   hipStream_t s = (hipStream_t)stream;
   const uint64_t nblocks_total = (size + kLogBlock - 1) / kLogBlock;
-  // Slices of at most 1 GiB keep the descriptor scratch modest.  Each slice needs one
-  // host round trip (the record count sizes the descriptor list).
-  const uint64_t slice_blocks = 32768;
+  // One slice is up to 8 GiB (the walk kernels are latency-bound, so fewer, larger launches are
+  // cheaper).  Each slice needs one host round trip: the record count sizes the descriptor list.
+  const uint64_t slice_blocks = 262144;
   uint64_t total_records = 0;
   for (uint64_t b0 = 0; b0 < nblocks_total; b0 += slice_blocks) {
     const uint32_t nb = (uint32_t)(nblocks_total - b0 < slice_blocks ? nblocks_total - b0 : slice_blocks);

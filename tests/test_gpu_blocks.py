@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CAP = json.load(open(os.path.join(HERE, "golden", "reference_captured.json")))
 
 
-@pytest.fixture(scope="module", params=[8, 16, 64])
+@pytest.fixture(scope="module", params=[4, 8, 16, 64])
 def eng(request):
     import gpu_util as G
     e = G.engine(request.param)

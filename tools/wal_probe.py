@@ -15,7 +15,7 @@ import terarkdb_amd.capi as capi  # noqa: E402
 
 OL = O.lib()
 n_rec = int(os.environ.get("MP_RECORDS", "500000"))
-eng = capi.Engine(0)
+import gpu_util as G
 t = O.OracleLog(recycle=False, log_number=7, hw=True)
 OL.oracle_wal_write_dbbench_records(t.writer, n_rec, 301)
 size = t.written_bytes()
@@ -25,7 +25,11 @@ dev = torch.from_numpy(img).cuda()
 nb = (size + 32767) // 32768
 blocks = torch.zeros((nb, 4), dtype=torch.int32, device="cuda")
 counts = torch.zeros(3, dtype=torch.int64, device="cuda")
-for i in range(6):
+for i in range(8):
+    if i % 4 == 0:
+        lanes = (8, 4)[(i // 4) % 2]
+        eng = G.engine(lanes)
+        print("lanes per record:", lanes)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     eng.counts_reset(counts)
