@@ -128,7 +128,8 @@ typedef struct tcrc_wal_block {
  * log::Reader::ReadPhysicalRecord does with checksum=true (db/log_reader.cc:314-406):
  * d_blocks[b] describes block b = bytes [32768*b, 32768*(b+1)) of the image.  Within a
  * block the reference stops at the first bad checksum, so first_bad is what its policy
- * layer needs.  d_counts accumulates TCRC_CNT_* over all candidate records.  Synchronises
+ * layer needs.  d_counts accumulates TCRC_CNT_* over all candidate records (TCRC_CNT_FIRST_BAD
+ * is the index of the first 32 KiB block that holds a mismatching record).  Synchronises
  * the stream once per 8 GiB (the record count is needed on the host); on return the rest
  * of the work is enqueued on `stream`.  *h_records, if not NULL, receives the number of
  * candidate records. */

@@ -33,6 +33,18 @@ inline uint32_t gf2_xpow(uint64_t e) {
   return r;
 }
 
+// x^(-8n) mod P: the register that, advanced through n zero bytes, becomes 1.  x is a unit
+// because P has a constant term, and dividing by x undoes one multiply-by-x step exactly.
+inline uint32_t gf2_xinv_bytes(uint32_t n) {
+  uint32_t r = 0x80000000u;  // 1
+  for (uint32_t i = 0; i < 8 * n; ++i) {
+    const uint32_t carried = r >> 31;  // the bit the forward step moved in from x^32
+    if (carried) r ^= kPolyReflected;
+    r = (r << 1) | carried;
+  }
+  return r;
+}
+
 // Register r after nbytes further zero bytes.
 inline uint32_t gf2_shift_bytes(uint32_t r, uint64_t nbytes) { return gf2_mulmod(r, gf2_xpow(8 * nbytes)); }
 

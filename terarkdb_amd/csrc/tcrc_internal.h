@@ -32,6 +32,7 @@ struct BatchParams {
   const unsigned long long* n_dev;  // when set, the batch size is read from device memory (<= n)
   const uint32_t* item_block;       // kFlagWalItems: 32 KiB block index of every item
   tcrc_wal_block* wal_blocks;       // kFlagWalItems: per block result (first_bad is lowered on a mismatch)
+  uint64_t wal_block_base;          // kFlagWalItems: index of wal_blocks[0] in the whole image
   const uint32_t* seg_owner;        // kFlagSegments: output slot (buffer index) of every segment
   const uint32_t* seg_after;        // kFlagSegments: number of whole segments that follow it in its buffer
   const uint32_t* seg_pow;          // kFlagSegments: seg_pow[q] = x^(8 * segment_len * q) mod P
@@ -70,13 +71,13 @@ struct tcrc_ctx {
   uint32_t* d_tab_aux[tcrc_internal::kGeoCount] = {};
   std::string description;
   // log-scan scratch (tcrc_wal.hip)
-  tcrc_scratch wal_counts, wal_first, wal_items, wal_item_block, wal_misc;
+  tcrc_scratch wal_items, wal_item_block, wal_misc;
   // host-pointer entry points (tcrc_host.hip): their own stream and staging, one call at a time
   std::mutex host_mu;
   hipStream_t host_stream = nullptr;
   tcrc_scratch host_data, host_desc, host_out, host_aux, host_blocks;
   // long-buffer scratch (tcrc_long.hip), guarded by host_mu
-  tcrc_scratch long_in, long_desc, long_owner, long_after, long_pow;
+  tcrc_scratch long_in, long_desc, long_owner, long_after, long_pow, long_acc;
   uint32_t long_pow_seg = 0;      // segment length the cached power table was built for
   uint32_t long_pow_count = 0;    // entries in it
 };

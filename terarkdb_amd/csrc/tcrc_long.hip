@@ -11,6 +11,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <string.h>
+
 #include <string>
 #include <vector>
 
@@ -57,6 +59,12 @@ __global__ __launch_bounds__(256) void k_expand_segments(ExpandParams p) {
   p.after[s] = q;
 }
 
+// The kernel accumulates buffer b in acc[32 b] (one accumulator per 128-byte line).
+__global__ __launch_bounds__(256) void k_long_gather(const uint32_t* acc, uint32_t* out, uint32_t n) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i < n) out[i] = acc[(uint64_t)i * 32u];
+}
+
 // seg_pow[q] = x^(8 * seg_len * q), grown on demand and cached per context.
 int ensure_pow_table(tcrc_ctx* ctx, uint32_t seg_len, uint32_t count, hipStream_t s) {
   if (ctx->long_pow_seg == seg_len && ctx->long_pow_count >= count) return TCRC_OK;
@@ -98,7 +106,10 @@ extern "C" int tcrc_dev_extend_long(tcrc_ctx* ctx, const void* d_base, const tcr
     while (seg < 65536 && total / seg > groups) seg <<= 1;
   }
   if (seg < 256 || (seg & (seg - 1)) != 0) return fail(TCRC_ERR_INVALID, "segment_len must be a power of two >= 256");
-  std::vector<uint32_t> first(n + 1);
+  // one staging block: the descriptors, then the running segment counts
+  std::vector<uint32_t> staging(n * 4 + n + 1);
+  memcpy(staging.data(), h_desc, n * sizeof(tcrc_desc));
+  uint32_t* first = staging.data() + n * 4;
   uint64_t nseg = 0;
   for (uint64_t i = 0; i < n; ++i) {
     first[i] = (uint32_t)nseg;
@@ -116,9 +127,9 @@ extern "C" int tcrc_dev_extend_long(tcrc_ctx* ctx, const void* d_base, const tcr
   if (int rc = scratch_reserve(ctx, &ctx->long_owner, nseg * 4)) return rc;
   if (int rc = scratch_reserve(ctx, &ctx->long_after, nseg * 4)) return rc;
   uint8_t* in = (uint8_t*)ctx->long_in.p;
-  HIP_TRY(hipMemcpyAsync(in, h_desc, n * sizeof(tcrc_desc), hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync(in + n * sizeof(tcrc_desc), first.data(), (n + 1) * 4, hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemsetAsync(d_out, 0, n * 4, s));
+  HIP_TRY(hipMemcpyAsync(in, staging.data(), in_bytes, hipMemcpyHostToDevice, s));
+  if (int rc = scratch_reserve(ctx, &ctx->long_acc, n * 128)) return rc;
+  HIP_TRY(hipMemsetAsync(ctx->long_acc.p, 0, n * 128, s));
   ExpandParams e{};
   e.buffers = (const tcrc_desc*)in;
   e.seg_first = (const uint32_t*)(in + n * sizeof(tcrc_desc));
@@ -136,12 +147,15 @@ extern "C" int tcrc_dev_extend_long(tcrc_ctx* ctx, const void* d_base, const tcr
   p.n = nseg;
   p.uniform_suffix = -1;
   p.flags = kFlagSegments;
-  p.out = d_out;
+  p.out = (uint32_t*)ctx->long_acc.p;
   p.seg_owner = e.owner;
   p.seg_after = e.after;
   p.seg_pow = (const uint32_t*)ctx->long_pow.p;
   if (int rc = run_batch(ctx, p, stream)) return rc;
-  // first[] and h_desc were copied with pageable-memory semantics; make sure they are consumed
+  hipLaunchKernelGGL(k_long_gather, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
+                     (const uint32_t*)ctx->long_acc.p, d_out, (uint32_t)n);
+  HIP_TRY(hipGetLastError());
+  // the staging block was copied with pageable-memory semantics; make sure it is consumed
   HIP_TRY(hipStreamSynchronize(s));
   return TCRC_OK;
 }

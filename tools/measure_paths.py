@@ -241,11 +241,27 @@ def main():
     long_res = {}
     for sz in (256 * 1024, 1024 * 1024, 4 * 1024 * 1024):
         o1 = torch.zeros(1, dtype=torch.int32, device="cuda")
-        t1 = wall(lambda: eng.extend_long(dS, [0], [sz], [0], o1), reps=20)
+        d1 = (capi.Desc * 1)()
+        d1[0].offset, d1[0].len, d1[0].init = 0, sz, 0
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+        def run1():
+            capi.check(L.tcrc_dev_extend_long(eng.ctx, C.c_void_p(dS.data_ptr()), d1, 1, 0,
+                                              C.c_void_p(o1.data_ptr()), stream))
+
+        t1 = wall(run1, reps=20)
         assert int(o1.cpu().numpy().view(np.uint32)[0]) == O.value(S[:sz], "hw")
         offs = [i * sz for i in range(64)]
         o64 = torch.zeros(64, dtype=torch.int32, device="cuda")
-        t64 = wall(lambda: eng.extend_long(dS, offs, [sz] * 64, [0] * 64, o64), reps=20)
+        d64 = (capi.Desc * 64)()
+        for i in range(64):
+            d64[i].offset, d64[i].len, d64[i].init = offs[i], sz, 0
+
+        def run64():
+            capi.check(L.tcrc_dev_extend_long(eng.ctx, C.c_void_p(dS.data_ptr()), d64, 64, 0,
+                                              C.c_void_p(o64.data_ptr()), stream))
+
+        t64 = wall(run64, reps=20)
         want = O.batch_extend(S, np.array(offs, np.uint64), np.full(64, sz, np.uint32))
         assert (o64.cpu().numpy().view(np.uint32) == want).all()
         long_res[str(sz)] = {"single_us": round(t1 * 1e6, 1), "single_GBps": round(sz / t1 / 1e9, 1),
