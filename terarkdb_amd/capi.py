@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libtcrc.so")
+LIB_PATH = os.environ.get("TCRC_LIBRARY") or os.path.join(_HERE, "lib", "libtcrc.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

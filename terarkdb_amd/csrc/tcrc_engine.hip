@@ -239,7 +239,35 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p) {
     // inside a wave measured faster than keeping loads in flight across the folds; the other
     // waves of the CU cover the latency.  The Rmax mod 4 odd rows come first, one burst.
     uint32_t r = 0;
-    {
+    // The common shape - every buffer of the wave starts and ends on a row boundary and has the
+    // same number of rows, a multiple of four - needs no per-group checks at all: only lane 0 of
+    // each group folds the initial register into its first dword.
+    if ((Rmax & 3u) == 0u && __all(live && a0 == 0u && tpad == 0u && R == Rmax)) {
+      const uint8_t* q = ptr + 16 * j;
+      {
+        uint4 a = load16<NT>(q);
+        const uint4 b = load16<NT>(q + D);
+        const uint4 c = load16<NT>(q + 2 * D);
+        const uint4 d = load16<NT>(q + 3 * D);
+        if (j == 0) a.x ^= r0;
+        fold_plain(a);
+        fold_plain(b);
+        fold_plain(c);
+        fold_plain(d);
+      }
+      for (r = 4u; r < Rmax; r += 4u) {
+        q += 4 * D;
+        const uint4 a = load16<NT>(q);
+        const uint4 b = load16<NT>(q + D);
+        const uint4 c = load16<NT>(q + 2 * D);
+        const uint4 d = load16<NT>(q + 3 * D);
+        fold_plain(a);
+        fold_plain(b);
+        fold_plain(c);
+        fold_plain(d);
+      }
+    }
+    if (r == 0u) {
       const uint32_t head = Rmax & 3u;
       if (head) {
         const uint4 a = load_checked(0);
