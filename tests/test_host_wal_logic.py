@@ -75,3 +75,14 @@ def test_random_read_whole_file_verdicts_need_no_block_requests(recycle):
     cap = CAP["wal_random_read"]["recyclable" if recycle else "legacy"]
     assert t.written_bytes() == cap["file_size"]
     assert O.value(t.contents()) == int(cap["value_of_whole_file"], 16)
+
+
+@pytest.mark.parametrize("name", ["reference_MANIFEST-CORRECT.bin", "reference_MANIFEST-WRONG.bin"])
+def test_reference_manifest_files(name):
+    import manifest_cases as M
+    import terarkdb_amd.capi as capi
+
+    def put(t, b):
+        capi.lib.tcrc_shim_memfile_append(t.file, b, len(b))
+    M.roundtrip(mk, name, put)
+    M.roundtrip(mk_bulk, name, put)
