@@ -1,0 +1,119 @@
+"""GPU parity at the benchmark's full sizes: one GPU's 8 GiB shard of the multi-GPU corpus.
+
+The CPU oracle cannot redo 8 GiB inside a test, so the whole-corpus checks are size-independent
+properties (the fold of the first 1 GiB's trailers is a captured reference value; stamping then
+verifying is clean; M seeded corruptions give exactly M mismatches and the right first index),
+and the oracle checks samples taken from every part of the shard, including offsets past 4 GiB.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+CAP = json.load(open(os.path.join(HERE, "golden", "reference_captured.json")))
+
+BLEN = 8192
+GIB = 1 << 30
+
+
+def _fill_splitmix(buf, state):
+    """buf (uint8 device tensor, multiple of 8 bytes) <- the splitmix64 stream, made 256 MiB at a time."""
+    golden = -7046029254386353131
+    step = (256 << 20) // 8
+    words = buf.view(torch.int64)
+    for w0 in range(0, words.numel(), step):
+        n = min(step, words.numel() - w0)
+        z = torch.arange(w0 + 1, w0 + 1 + n, dtype=torch.int64, device="cuda") * golden + state
+
+        def lsr(x, k):
+            return (x >> k) & ((1 << (64 - k)) - 1)
+
+        z = (z ^ lsr(z, 30)) * -4658895280553007687
+        z = (z ^ lsr(z, 27)) * -7723592293110705685
+        words[w0:w0 + n] = z ^ lsr(z, 31)
+
+
+@pytest.fixture(scope="module")
+def shard():
+    import gpu_util as G
+    e = G.engine()
+    nblk = 8 * GIB // BLEN
+    data = torch.empty(8 * GIB, dtype=torch.uint8, device="cuda")
+    _fill_splitmix(data, 301)
+    yield e, data, nblk
+    e.close()
+    del data
+    torch.cuda.empty_cache()
+
+
+def test_eight_gib_shard_stamp_verify_and_corruptions(shard):
+    import terarkdb_amd.capi as capi
+    e, data, nblk = shard
+    stored = torch.zeros(nblk, dtype=torch.int32, device="cuda")
+    e.blocks_stamp(data, nblk, BLEN, BLEN, stored, suffix_byte=0, flags=capi.F_MASK)
+    torch.cuda.synchronize()
+    tr = stored.cpu().numpy().view(np.uint32)
+    # the first GiB is the single-GPU benchmark corpus: fold captured from a build of the reference
+    assert int(np.bitwise_xor.reduce(tr[:GIB // BLEN])) == int(CAP["sst_1gib_splitmix"]["xor_of_masked"], 16)
+    # oracle on samples from every part of the shard (block indices straddling every GiB boundary)
+    rng = np.random.default_rng(5)
+    idx = np.unique(np.concatenate([rng.integers(0, nblk, 600), [0, nblk - 1],
+                                    *[np.arange(g * (GIB // BLEN) - 2, g * (GIB // BLEN) + 2) for g in range(1, 8)]]))
+    blocks = data.view(nblk, BLEN)[torch.from_numpy(idx).cuda()].cpu().numpy()
+    assert (O.sst_trailer_batch(blocks, BLEN, BLEN, len(idx), 0) == tr[idx]).all()
+
+    counts = torch.zeros(capi.CNT_WORDS, dtype=torch.int64, device="cuda")
+    ok = torch.zeros(nblk, dtype=torch.uint8, device="cuda")
+    e.counts_reset(counts)
+    e.blocks_verify(data, nblk, BLEN, BLEN, counts, expected=stored, ok=ok, suffix_byte=0)
+    c = counts.cpu().numpy().view(np.uint64)
+    assert (int(c[capi.CNT_MISMATCH]), int(c[capi.CNT_CHECKED])) == (0, nblk)
+    assert int(c[capi.CNT_FIRST_BAD]) == 2**64 - 1 and bool(ok.all())
+
+    m = 37
+    bad = np.sort(np.random.default_rng(77).choice(nblk, m, replace=False))
+    bad[-1] = nblk - 1  # one in the very last block, past the 4 GiB offsets
+    flat = data.view(-1)
+    for b in bad:
+        pos = int(b) * BLEN + int(rng.integers(0, BLEN))
+        flat[pos] ^= 1 << int(rng.integers(0, 8))
+    e.counts_reset(counts)
+    e.blocks_verify(data, nblk, BLEN, BLEN, counts, expected=stored, ok=ok, suffix_byte=0)
+    c = counts.cpu().numpy().view(np.uint64)
+    assert (int(c[capi.CNT_MISMATCH]), int(c[capi.CNT_CHECKED])) == (len(set(bad.tolist())), nblk)
+    assert int(c[capi.CNT_FIRST_BAD]) == int(bad[0])
+    assert sorted(torch.nonzero(ok == 0).flatten().cpu().tolist()) == sorted(set(bad.tolist()))
+
+
+def test_descriptors_past_four_gib(shard):
+    import terarkdb_amd.capi as capi
+    e, data, nblk = shard
+    rng = np.random.default_rng(9)
+    n = 3000
+    offs = rng.integers(4 * GIB, 8 * GIB - 70000, n).astype(np.uint64)
+    lens = rng.integers(0, 66000, n).astype(np.uint32)
+    inits = rng.integers(0, 2**32, n).astype(np.uint32)
+    desc = capi.make_desc_tensor(offs, lens, inits, "cuda")
+    out = torch.zeros(n, dtype=torch.int32, device="cuda")
+    e.batch_stamp(data, desc, n, out, flags=0)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().view(np.uint32)
+    for i in range(0, n, 7):
+        o, l = int(offs[i]), int(lens[i])
+        assert int(got[i]) == O.extend(int(inits[i]), data[o:o + l].cpu().numpy().tobytes()), i
+    # long buffers reaching across the 4 GiB line
+    lo = [4 * GIB - 3 * (1 << 20) - 5, 6 * GIB + 11]
+    ll = [6 * (1 << 20) + 13, 4 * (1 << 20)]
+    li = [0, 0xdeadbeef]
+    out2 = torch.zeros(2, dtype=torch.int32, device="cuda")
+    e.extend_long(data, lo, ll, li, out2)
+    torch.cuda.synchronize()
+    got2 = out2.cpu().numpy().view(np.uint32)
+    for i in range(2):
+        assert int(got2[i]) == O.extend(li[i], data[lo[i]:lo[i] + ll[i]].cpu().numpy().tobytes())
