@@ -158,6 +158,15 @@ int tcrc_host_batch_verify(tcrc_ctx* ctx, const void* h_base, uint64_t base_byte
 int tcrc_host_wal_verify(tcrc_ctx* ctx, const void* h_img, uint64_t size, uint64_t log_number, tcrc_wal_block* h_blocks,
                          uint64_t* h_counts, uint64_t* h_records);
 
+/* The reference's scalar interface on host bytes: *out = crc32c::Extend(init, data, n)
+ * (util/crc32c.cc:1226-1228) and crc32c::Value(data, n) (util/crc32c.h:29), computed on the GPU
+ * (copy in, long-buffer kernels, 4 bytes back).  Unlike the reference's functions these can fail
+ * (no GPU, HIP error), so the value comes back through *out.  Any n; inputs above 256 MiB are fed
+ * in pieces chained through init.  One call costs a PCIe round trip: this is for whole files and
+ * large buffers (utilities/backupable/backupable_db.cc:1260-1263,1434-1449), not for one record. */
+int tcrc_extend(tcrc_ctx* ctx, uint32_t init, const void* h_data, size_t n, uint32_t* out);
+int tcrc_value(tcrc_ctx* ctx, const void* h_data, size_t n, uint32_t* out);
+
 /* ---- measurement aid ----------------------------------------------------------- */
 /* Streams nbytes from d_base with loads only (no checksum work) so a benchmark can report
  * the read rate this device actually reaches beside the CRC kernels' rate.  d_scratch

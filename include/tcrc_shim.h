@@ -81,6 +81,14 @@ int tcrc_shim_check_blocks(tcrc_ctx* ctx, const void* image, size_t image_size, 
                            const uint64_t* handle_offsets, const uint64_t* handle_sizes, size_t n, int checksum_type,
                            const char* file_name, uint8_t* ok_out, char* first_message, size_t first_message_cap);
 
+/* Whole-file crc32c as the backup engine computes it (utilities/backupable/backupable_db.cc:1414-1452
+ * CalculateChecksum; :1195-1283 CopyOrCreateFile): size_limit 0 = whole file; buffer_size 0 = default.
+ * Return 0, or -1 with the Status text in message (if not NULL). */
+int tcrc_shim_file_checksum(tcrc_ctx* ctx, const char* path, uint64_t size_limit, size_t buffer_size,
+                            uint32_t* checksum_out, uint64_t* size_out, char* message, size_t message_cap);
+int tcrc_shim_copy_file(tcrc_ctx* ctx, const char* src, const char* dst, uint64_t size_limit, size_t buffer_size,
+                        int sync, uint32_t* checksum_out, uint64_t* size_out, char* message, size_t message_cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -62,6 +62,8 @@ SIGNATURES.update({
     "tcrc_host_blocks_stamp": (_i, [_vp, _vp, _u64, _u32, _u64, _u32, _i, _u32, _vp]),
     "tcrc_host_batch_verify": (_i, [_vp, _vp, _u64, _vp, _u64, _vp, _u32, _vp, _vp, _vp, _vp]),
     "tcrc_host_wal_verify": (_i, [_vp, _vp, _u64, _u64, _vp, _vp, C.POINTER(_u64)]),
+    "tcrc_extend": (_i, [_vp, _u32, _vp, _sz, C.POINTER(_u32)]),
+    "tcrc_value": (_i, [_vp, _vp, _sz, C.POINTER(_u32)]),
     "tcrc_shim_memfile_new": (_vp, []),
     "tcrc_shim_memfile_free": (None, [_vp]),
     "tcrc_shim_memfile_size": (_sz, [_vp]),
@@ -96,6 +98,9 @@ SIGNATURES.update({
     "tcrc_shim_block_trailers": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _i, _vp]),
     "tcrc_shim_write_raw_blocks": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp]),
     "tcrc_shim_check_blocks": (_i, [_vp, _vp, _sz, _u64, _vp, _vp, _sz, _i, C.c_char_p, _vp, C.c_char_p, _sz]),
+    "tcrc_shim_file_checksum": (_i, [_vp, C.c_char_p, _u64, _sz, C.POINTER(_u32), C.POINTER(_u64), C.c_char_p, _sz]),
+    "tcrc_shim_copy_file": (_i, [_vp, C.c_char_p, C.c_char_p, _u64, _sz, _i, C.POINTER(_u32), C.POINTER(_u64),
+                                 C.c_char_p, _sz]),
 })
 for _name, (_res, _args) in SIGNATURES.items():
     _f = getattr(lib, _name)
@@ -177,6 +182,17 @@ class Engine:
         for i in range(n):
             arr[i].offset, arr[i].len, arr[i].init = int(offsets[i]), int(lens[i]), int(inits[i])
         check(lib.tcrc_dev_extend_long(self.ctx, _dp(base), arr, n, segment_len, _dp(out), self._stream(stream)))
+
+    def extend(self, init, data):
+        """crc32c::Extend(init, data) for host bytes (bytes, bytearray or a contiguous numpy array)."""
+        import numpy as np
+        a = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+        out = _u32(0)
+        check(lib.tcrc_extend(self.ctx, init, C.c_void_p(a.ctypes.data) if a.size else None, a.nbytes, C.byref(out)))
+        return out.value
+
+    def value(self, data):
+        return self.extend(0, data)
 
     def counts_reset(self, counts, stream=None):
         check(lib.tcrc_dev_counts_reset(self.ctx, _dp(counts), self._stream(stream)))

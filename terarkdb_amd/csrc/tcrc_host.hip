@@ -154,4 +154,38 @@ int tcrc_host_wal_verify(tcrc_ctx* ctx, const void* h_img, uint64_t size, uint64
   return TCRC_OK;
 }
 
+int tcrc_extend(tcrc_ctx* ctx, uint32_t init, const void* h_data, size_t n, uint32_t* out) {
+  if (!ctx) return fail(TCRC_ERR_INVALID, "null context");
+  if (!out) return fail(TCRC_ERR_INVALID, "null argument");
+  *out = init;  // Extend over no bytes leaves the value as it is
+  if (n == 0) return TCRC_OK;
+  if (!h_data) return fail(TCRC_ERR_INVALID, "null argument");
+  std::lock_guard<std::mutex> lock(ctx->host_mu);
+  if (int rc = host_begin(ctx)) return rc;
+  // Pieces of up to 256 MiB, chained through init like the callers that feed a file through
+  // Extend buffer by buffer (utilities/backupable/backupable_db.cc:1434-1449).
+  const size_t piece = (size_t)256 << 20;
+  if (int rc = scratch_reserve(ctx, &ctx->host_out, 64)) return rc;
+  uint32_t crc = init;
+  for (size_t done = 0; done < n;) {
+    const size_t len = n - done < piece ? n - done : piece;
+    if (int rc = upload(ctx, &ctx->host_data, (const uint8_t*)h_data + done, len)) return rc;
+    tcrc_desc d;
+    d.offset = 0;
+    d.len = (uint32_t)len;
+    d.init = crc;
+    if (int rc = tcrc_dev_extend_long(ctx, ctx->host_data.p, &d, 1, 0, (uint32_t*)ctx->host_out.p, ctx->host_stream))
+      return rc;
+    HIP_TRY(hipMemcpyAsync(&crc, ctx->host_out.p, 4, hipMemcpyDeviceToHost, ctx->host_stream));
+    HIP_TRY(hipStreamSynchronize(ctx->host_stream));
+    done += len;
+  }
+  *out = crc;
+  return TCRC_OK;
+}
+
+int tcrc_value(tcrc_ctx* ctx, const void* h_data, size_t n, uint32_t* out) {
+  return tcrc_extend(ctx, 0, h_data, n, out);
+}
+
 }  // extern "C"

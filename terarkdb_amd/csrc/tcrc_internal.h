@@ -70,13 +70,16 @@ struct tcrc_ctx {
   uint32_t* d_tab_main[tcrc_internal::kGeoCount] = {};
   uint32_t* d_tab_aux[tcrc_internal::kGeoCount] = {};
   std::string description;
-  // log-scan scratch (tcrc_wal.hip)
+  // log-scan scratch (tcrc_wal.hip): one scan at a time per context
+  std::mutex wal_mu;
   tcrc_scratch wal_items, wal_item_block, wal_misc;
   // host-pointer entry points (tcrc_host.hip): their own stream and staging, one call at a time
   std::mutex host_mu;
   hipStream_t host_stream = nullptr;
   tcrc_scratch host_data, host_desc, host_out, host_aux, host_blocks;
-  // long-buffer scratch (tcrc_long.hip), guarded by host_mu
+  // long-buffer scratch (tcrc_long.hip): one call at a time per context.  Lock order: host_mu, then
+  // wal_mu or long_mu.
+  std::mutex long_mu;
   tcrc_scratch long_in, long_desc, long_owner, long_after, long_pow, long_acc;
   uint32_t long_pow_seg = 0;      // segment length the cached power table was built for
   uint32_t long_pow_count = 0;    // entries in it

@@ -119,7 +119,7 @@ extern "C" int tcrc_dev_extend_long(tcrc_ctx* ctx, const void* d_base, const tcr
   first[n] = (uint32_t)nseg;
   if (nseg >= (1ull << 31)) return fail(TCRC_ERR_TOO_LARGE, "too many segments");
 
-  std::lock_guard<std::mutex> lock(ctx->host_mu);
+  std::lock_guard<std::mutex> lock(ctx->long_mu);
   if (int rc = ensure_pow_table(ctx, seg, (uint32_t)((longest + seg - 1) / seg + 1), s)) return rc;
   const size_t in_bytes = n * sizeof(tcrc_desc) + (n + 1) * 4;
   if (int rc = scratch_reserve(ctx, &ctx->long_in, in_bytes)) return rc;

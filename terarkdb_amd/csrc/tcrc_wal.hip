@@ -163,6 +163,7 @@ extern "C" int tcrc_dev_wal_verify(tcrc_ctx* ctx, const void* d_img, uint64_t si
   if (size == 0) return TCRC_OK;
   if (!d_img || !d_blocks || !d_counts) return fail(TCRC_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(ctx->device));
+  std::lock_guard<std::mutex> lock(ctx->wal_mu);  // the descriptor scratch belongs to one scan at a time
   hipStream_t s = (hipStream_t)stream;
   const uint64_t nblocks_total = (size + kLogBlock - 1) / kLogBlock;
   // One slice is up to 8 GiB (the walk is latency-bound, so fewer, larger launches are cheaper).

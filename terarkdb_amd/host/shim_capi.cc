@@ -1,5 +1,6 @@
 // C entry points over the C++ writer/reader/trailer classes, so that bindings and tests
 // can drive them without a C++ compiler.  Declared in include/tcrc_shim.h.
+#include <stdio.h>
 #include <string.h>
 
 #include <memory>
@@ -8,6 +9,7 @@
 
 #include "../../include/tcrc_shim.h"
 #include "block_trailer.h"
+#include "file_checksum.h"
 #include "files.h"
 #include "wal_reader.h"
 #include "wal_writer.h"
@@ -280,6 +282,30 @@ int tcrc_shim_check_blocks(tcrc_ctx* ctx, const void* image, size_t image_size, 
     first_message[first_message_cap - 1] = 0;
   }
   return first.ok() ? 0 : 1;
+}
+
+int tcrc_shim_file_checksum(tcrc_ctx* ctx, const char* path, uint64_t size_limit, size_t buffer_size,
+                            uint32_t* checksum_out, uint64_t* size_out, char* message, size_t message_cap) {
+  uint32_t crc = 0;
+  uint64_t size = 0;
+  Status s = CalculateChecksum(ctx, std::string(path), size_limit, &crc, &size,
+                               buffer_size ? buffer_size : kDefaultChecksumBufferSize);
+  if (checksum_out) *checksum_out = crc;
+  if (size_out) *size_out = size;
+  if (message && message_cap) snprintf(message, message_cap, "%s", s.ToString().c_str());
+  return s.ok() ? 0 : -1;
+}
+
+int tcrc_shim_copy_file(tcrc_ctx* ctx, const char* src, const char* dst, uint64_t size_limit, size_t buffer_size,
+                        int sync, uint32_t* checksum_out, uint64_t* size_out, char* message, size_t message_cap) {
+  uint32_t crc = 0;
+  uint64_t size = 0;
+  Status s = CopyOrCreateFile(ctx, std::string(src), std::string(dst), std::string(), sync != 0, &size, &crc,
+                              size_limit, buffer_size ? buffer_size : kDefaultChecksumBufferSize);
+  if (checksum_out) *checksum_out = crc;
+  if (size_out) *size_out = size;
+  if (message && message_cap) snprintf(message, message_cap, "%s", s.ToString().c_str());
+  return s.ok() ? 0 : -1;
 }
 
 }  // extern "C"
