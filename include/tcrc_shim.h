@@ -81,6 +81,31 @@ int tcrc_shim_check_blocks(tcrc_ctx* ctx, const void* image, size_t image_size, 
                            const uint64_t* handle_offsets, const uint64_t* handle_sizes, size_t n, int checksum_type,
                            const char* file_name, uint8_t* ok_out, char* first_message, size_t first_message_cap);
 
+/* Whole-file checksum verification of a block-based table file: BlockBasedTable::VerifyChecksum
+ * (table/block_based_table_reader.cc:2616-2695) as reached from VerifySstFileChecksum
+ * (db/convenience.cc:35-64) and `sst_dump --command=verify` (tools/sst_dump_tool.cc:656-665).
+ * extent_bytes / read_threads 0 = defaults; index_type_hint = BlockBasedTableOptions::index_type to assume
+ * when the file does not say.  stats_out (may be NULL) receives 7 values: file size, meta blocks, index
+ * blocks, data blocks, bytes covered, mismatching blocks, engine calls.  message receives Status::ToString().
+ * Returns 0 OK, 1 Corruption, 2 NotSupported (declined: xxHash checksums, compressed index), -1 other. */
+int tcrc_shim_sst_verify(tcrc_ctx* ctx, const char* path, size_t extent_bytes, int read_threads, int index_type_hint,
+                         uint64_t* stats_out, char* message, size_t message_cap);
+/* The same driver with the checksum arithmetic supplied by the caller (tests of the host logic). */
+typedef int (*tcrc_shim_check_fn)(void* user, const void* image, size_t image_bytes, const tcrc_desc* spans, size_t n,
+                                  uint32_t* computed_masked, uint8_t* ok);
+int tcrc_shim_sst_verify_cb(tcrc_shim_check_fn fn, void* user, const char* path, size_t extent_bytes, int read_threads,
+                            int index_type_hint, uint64_t* stats_out, char* message, size_t message_cap);
+
+/* `ldb dump_wal` (tools/ldb_cmd.cc:1967-2037): checks every record of the log file on the GPU, then
+ * writes the rows ("Sequence,Count,ByteSize,Physical Offset,Key(s)" ...) to out and the
+ * "Corruption detected in log file ..." lines to err, both NUL-terminated and cut at their caps;
+ * *out_len / *err_len (may be NULL) receive the untruncated lengths.  Returns 0, or -1 when the file
+ * cannot be read or the engine fails (err then ends with the Status text). */
+int tcrc_shim_dump_wal(tcrc_ctx* ctx, const char* path, int print_header, int print_values, char* out, size_t out_cap,
+                       size_t* out_len, char* err, size_t err_cap, size_t* err_len);
+int tcrc_shim_dump_wal_cb(tcrc_shim_scan_fn fn, void* user, const char* path, int print_header, int print_values,
+                          char* out, size_t out_cap, size_t* out_len, char* err, size_t err_cap, size_t* err_len);
+
 /* Whole-file crc32c as the backup engine computes it (utilities/backupable/backupable_db.cc:1414-1452
  * CalculateChecksum; :1195-1283 CopyOrCreateFile): size_limit 0 = whole file; buffer_size 0 = default.
  * Return 0, or -1 with the Status text in message (if not NULL). */

@@ -55,6 +55,7 @@ SIGNATURES = {
 _sz = C.c_size_t
 STAMP_FN = C.CFUNCTYPE(_i, _vp, _vp, _sz, C.POINTER(Desc), _sz, C.POINTER(_u32))
 SCAN_FN = C.CFUNCTYPE(_i, _vp, _vp, _sz, _u64, C.POINTER(WalBlock))
+CHECK_FN = C.CFUNCTYPE(_i, _vp, _vp, _sz, C.POINTER(Desc), _sz, C.POINTER(_u32), C.POINTER(C.c_uint8))
 SIGNATURES.update({
     "tcrc_host_alloc": (_vp, [_vp, _sz]),
     "tcrc_host_free": (None, [_vp, _vp]),
@@ -98,6 +99,12 @@ SIGNATURES.update({
     "tcrc_shim_block_trailers": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _i, _vp]),
     "tcrc_shim_write_raw_blocks": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp]),
     "tcrc_shim_check_blocks": (_i, [_vp, _vp, _sz, _u64, _vp, _vp, _sz, _i, C.c_char_p, _vp, C.c_char_p, _sz]),
+    "tcrc_shim_sst_verify": (_i, [_vp, C.c_char_p, _sz, _i, _i, C.POINTER(_u64), C.c_char_p, _sz]),
+    "tcrc_shim_sst_verify_cb": (_i, [CHECK_FN, _vp, C.c_char_p, _sz, _i, _i, C.POINTER(_u64), C.c_char_p, _sz]),
+    "tcrc_shim_dump_wal": (_i, [_vp, C.c_char_p, _i, _i, C.c_char_p, _sz, C.POINTER(_sz), C.c_char_p, _sz,
+                                C.POINTER(_sz)]),
+    "tcrc_shim_dump_wal_cb": (_i, [SCAN_FN, _vp, C.c_char_p, _i, _i, C.c_char_p, _sz, C.POINTER(_sz), C.c_char_p, _sz,
+                                   C.POINTER(_sz)]),
     "tcrc_shim_file_checksum": (_i, [_vp, C.c_char_p, _u64, _sz, C.POINTER(_u32), C.POINTER(_u64), C.c_char_p, _sz]),
     "tcrc_shim_copy_file": (_i, [_vp, C.c_char_p, C.c_char_p, _u64, _sz, _i, C.POINTER(_u32), C.POINTER(_u64),
                                  C.c_char_p, _sz]),

@@ -10,6 +10,8 @@
 #include "../../include/tcrc_shim.h"
 #include "block_trailer.h"
 #include "file_checksum.h"
+#include "sst_verify.h"
+#include "wal_dump.h"
 #include "files.h"
 #include "wal_reader.h"
 #include "wal_writer.h"
@@ -282,6 +284,83 @@ int tcrc_shim_check_blocks(tcrc_ctx* ctx, const void* image, size_t image_size, 
     first_message[first_message_cap - 1] = 0;
   }
   return first.ok() ? 0 : 1;
+}
+
+namespace {
+class CallbackBlockChecker : public BlockBatchChecker {
+ public:
+  CallbackBlockChecker(tcrc_shim_check_fn fn, void* user) : fn_(fn), user_(user) {}
+  Status Check(const char* image, size_t image_bytes, const tcrc_desc* spans, size_t n, uint32_t* computed_masked,
+               uint8_t* ok) override {
+    if (fn_(user_, image, image_bytes, spans, n, computed_masked, ok) != 0)
+      return Status::IOError("check callback failed");
+    return Status::OK();
+  }
+
+ private:
+  tcrc_shim_check_fn fn_;
+  void* user_;
+};
+
+int SstVerifyWith(BlockBatchChecker* checker, const char* path, size_t extent_bytes, int read_threads,
+                  int index_type_hint, uint64_t* stats_out, char* message, size_t message_cap) {
+  SstVerifyOptions opt;
+  if (extent_bytes) opt.extent_bytes = extent_bytes;
+  if (read_threads) opt.read_threads = read_threads;
+  opt.index_type_hint = index_type_hint;
+  SstVerifyStats st;
+  std::unique_ptr<RandomAccessFile> file;
+  Status s = NewPosixRandomAccessFile(path, &file);
+  if (s.ok()) s = VerifySstFileChecksum(checker, file.get(), path, opt, &st);
+  if (stats_out) {
+    const uint64_t v[7] = {st.file_size,     st.meta_blocks, st.index_blocks, st.data_blocks,
+                           st.bytes_covered, st.mismatches,  st.engine_calls};
+    memcpy(stats_out, v, sizeof(v));
+  }
+  if (message && message_cap) snprintf(message, message_cap, "%s", s.ToString().c_str());
+  if (s.ok()) return 0;
+  if (s.IsCorruption()) return 1;
+  if (s.code() == Status::kNotSupported) return 2;
+  return -1;
+}
+}  // namespace
+
+int tcrc_shim_sst_verify(tcrc_ctx* ctx, const char* path, size_t extent_bytes, int read_threads, int index_type_hint,
+                         uint64_t* stats_out, char* message, size_t message_cap) {
+  DeviceBlockBatchChecker checker(ctx);
+  return SstVerifyWith(&checker, path, extent_bytes, read_threads, index_type_hint, stats_out, message, message_cap);
+}
+
+int tcrc_shim_sst_verify_cb(tcrc_shim_check_fn fn, void* user, const char* path, size_t extent_bytes, int read_threads,
+                            int index_type_hint, uint64_t* stats_out, char* message, size_t message_cap) {
+  CallbackBlockChecker checker(fn, user);
+  return SstVerifyWith(&checker, path, extent_bytes, read_threads, index_type_hint, stats_out, message, message_cap);
+}
+
+namespace {
+int DumpWalWith(log::RecordVerifier* verifier, const char* path, int print_header, int print_values, char* out,
+                size_t out_cap, size_t* out_len, char* err, size_t err_cap, size_t* err_len) {
+  std::string o, e;
+  Status s = DumpWalFile(verifier, path, print_header != 0, print_values != 0, &o, &e);
+  if (!s.ok()) e += s.ToString() + "\n";
+  if (out && out_cap) snprintf(out, out_cap, "%s", o.c_str());
+  if (err && err_cap) snprintf(err, err_cap, "%s", e.c_str());
+  if (out_len) *out_len = o.size();
+  if (err_len) *err_len = e.size();
+  return s.ok() ? 0 : -1;
+}
+}  // namespace
+
+int tcrc_shim_dump_wal(tcrc_ctx* ctx, const char* path, int print_header, int print_values, char* out, size_t out_cap,
+                       size_t* out_len, char* err, size_t err_cap, size_t* err_len) {
+  log::DeviceRecordVerifier verifier(ctx);
+  return DumpWalWith(&verifier, path, print_header, print_values, out, out_cap, out_len, err, err_cap, err_len);
+}
+
+int tcrc_shim_dump_wal_cb(tcrc_shim_scan_fn fn, void* user, const char* path, int print_header, int print_values,
+                          char* out, size_t out_cap, size_t* out_len, char* err, size_t err_cap, size_t* err_len) {
+  CallbackVerifier verifier(fn, user);
+  return DumpWalWith(&verifier, path, print_header, print_values, out, out_cap, out_len, err, err_cap, err_len);
 }
 
 int tcrc_shim_file_checksum(tcrc_ctx* ctx, const char* path, uint64_t size_limit, size_t buffer_size,

@@ -1,0 +1,132 @@
+// Whole-file checksum verification of a block-based table file: the work of
+// BlockBasedTable::VerifyChecksum / VerifyChecksumInBlocks
+// (table/block_based_table_reader.cc:2616-2695) as reached from VerifySstFileChecksum
+// (db/convenience.cc:35-64), DBImpl::VerifyChecksum (db/db_impl.cc:4657-4690) and
+// `sst_dump --command=verify` (tools/sst_dump_tool.cc:161-163,656-665).
+//
+// The host side only enumerates: footer (table/format.cc:158-210), metaindex block, index
+// block(s) -> lists of (offset, size) handles.  Every block named by those lists, the
+// metaindex and index blocks included, is then checked by the engine in batches:
+// Unmask(fixed32 after the type byte) against crc32c(contents | type)
+// (table/block_fetcher.cc:36-71), with the reference's Corruption texts.
+//
+// Order of checks, which decides the status returned when several blocks are bad:
+// metaindex block; the meta blocks in metaindex (key) order; the index block; then data
+// blocks in index order - for a two-level index each partition block before its data blocks.
+#pragma once
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/tcrc.h"
+#include "block_trailer.h"
+#include "files.h"
+#include "status.h"
+
+namespace terarkdb_amd {
+
+const uint64_t kBlockBasedTableMagicNumber = 0x88e241b785f4cff7ull;        // table/block_based_table_builder.cc:190
+const uint64_t kLegacyBlockBasedTableMagicNumber = 0xdb4775248b80fb57ull;  // :193
+
+struct Footer {  // table/format.h:103-200
+  enum {
+    kVersion0EncodedLength = 2 * 20 + 8,         // two padded handles + magic
+    kNewVersionsEncodedLength = 1 + 2 * 20 + 4 + 8,  // checksum type, handles, version, magic
+    kMinEncodedLength = kVersion0EncodedLength,
+    kMaxEncodedLength = kNewVersionsEncodedLength,
+  };
+  uint32_t version = 0;
+  int checksum = kCRC32c;  // raw value as stored (may be one this engine does not know)
+  BlockHandle metaindex_handle;
+  BlockHandle index_handle;
+  uint64_t table_magic_number = 0;  // legacy magic is reported up-converted, like the reference
+
+  // *input holds at least the last kMinEncodedLength bytes of the file (table/format.cc:158-210).
+  Status DecodeFrom(Slice* input);
+  void EncodeTo(std::string* dst, bool legacy) const;  // table/format.cc:125-148
+};
+
+Status ReadFooterFromFile(const RandomAccessFile* file, uint64_t file_size, const std::string& file_name,
+                          Footer* footer, uint64_t enforce_table_magic_number = 0);
+
+// Entries of an uncompressed block in storage order (table/block.cc:39-97,526-606).
+// index_values_delta_encoded selects the format_version >= 4 index layout, where values are
+// block handles stored as (offset, size) at restart points and as a size delta elsewhere.
+class BlockCursor {
+ public:
+  BlockCursor(const Slice& contents, bool index_values_delta_encoded = false);
+  bool Next();  // false at the end or on error (see status())
+  const std::string& key() const { return key_; }
+  Slice value() const { return value_; }
+  const BlockHandle& handle() const { return handle_; }  // delta-encoded index blocks only
+  Status status() const { return status_; }
+
+ private:
+  const char* data_;
+  uint32_t restarts_ = 0;  // offset of the restart array
+  uint32_t next_ = 0;
+  bool delta_;
+  std::string key_;
+  Slice value_;
+  BlockHandle handle_;
+  Status status_;
+};
+
+// Where the checksum arithmetic happens: one call checks a batch of blocks that lie in one host
+// image.  spans[i] covers contents and type byte of block i; its stored fixed32 follows the span.
+// computed_masked[i] receives Mask(crc32c(span)), ok[i] whether it equals the stored value.
+class BlockBatchChecker {
+ public:
+  virtual ~BlockBatchChecker() {}
+  virtual Status Check(const char* image, size_t image_bytes, const tcrc_desc* spans, size_t n,
+                       uint32_t* computed_masked, uint8_t* ok) = 0;
+  // Staging memory for file extents (the device implementation hands out pinned memory).
+  virtual char* AllocStaging(size_t bytes) { return new char[bytes ? bytes : 1]; }
+  virtual void FreeStaging(char* p) { delete[] p; }
+};
+
+// The engine: tcrc_host_batch_verify on the context's GPU.
+class DeviceBlockBatchChecker : public BlockBatchChecker {
+ public:
+  explicit DeviceBlockBatchChecker(tcrc_ctx* ctx) : ctx_(ctx) {}
+  Status Check(const char* image, size_t image_bytes, const tcrc_desc* spans, size_t n, uint32_t* computed_masked,
+               uint8_t* ok) override;
+  char* AllocStaging(size_t bytes) override;
+  void FreeStaging(char* p) override;
+
+ private:
+  tcrc_ctx* ctx_;
+};
+
+struct SstVerifyOptions {
+  // Data blocks are read and submitted in runs of up to this many file bytes.
+  size_t extent_bytes = 256u << 20;
+  // Threads that pread one extent into the pinned staging buffer.
+  int read_threads = 8;
+  // BlockBasedTableOptions::index_type to assume when the file's properties do not name one
+  // (0 binary search, 1 hash search, 2 two-level; include/rocksdb/table.h).
+  int index_type_hint = 0;
+};
+
+struct SstVerifyStats {
+  uint64_t file_size = 0;
+  uint64_t meta_blocks = 0;   // metaindex block and the blocks it names
+  uint64_t index_blocks = 0;  // index block and, for a two-level index, its partitions
+  uint64_t data_blocks = 0;
+  uint64_t bytes_covered = 0;  // bytes the checksums cover (contents + type byte)
+  uint64_t mismatches = 0;     // blocks whose checksum did not match (all of them, not only the first)
+  uint64_t engine_calls = 0;
+};
+
+// Returns OK, the first Corruption in the order above, NotSupported when the footer names an
+// xxHash checksum kind or the index block is compressed (those stay with the host code), or an
+// I/O / engine error.
+Status VerifySstFileChecksum(BlockBatchChecker* checker, const RandomAccessFile* file, const std::string& file_name,
+                             const SstVerifyOptions& options = SstVerifyOptions(), SstVerifyStats* stats = nullptr);
+Status VerifySstFileChecksum(tcrc_ctx* ctx, const RandomAccessFile* file, const std::string& file_name,
+                             const SstVerifyOptions& options = SstVerifyOptions(), SstVerifyStats* stats = nullptr);
+Status VerifySstFileChecksum(tcrc_ctx* ctx, const std::string& path, const SstVerifyOptions& options = SstVerifyOptions(),
+                             SstVerifyStats* stats = nullptr);
+
+}  // namespace terarkdb_amd

@@ -153,3 +153,15 @@ def test_reference_manifest_files_on_device(eng, name):
         capi.lib.tcrc_shim_memfile_append(t.file, b, len(b))
     M.roundtrip(factory(eng), name, put)
     M.roundtrip(factory(eng, bulk_image=True), name, put)
+
+
+@pytest.mark.parametrize("case_name", ["clean_log", "corrupted_log", "manifest_named_file"])
+def test_dump_wal_on_device(case_name, tmp_path):
+    import gpu_util as G
+    import wal_dump_cases
+    import wal_dump_util
+    e = G.engine()
+    try:
+        getattr(wal_dump_cases, case_name)(wal_dump_util.dump_with_engine(e), str(tmp_path))
+    finally:
+        e.close()

@@ -86,3 +86,10 @@ def test_reference_manifest_files(name):
         capi.lib.tcrc_shim_memfile_append(t.file, b, len(b))
     M.roundtrip(mk, name, put)
     M.roundtrip(mk_bulk, name, put)
+
+
+@pytest.mark.parametrize("case_name", ["clean_log", "corrupted_log", "manifest_named_file"])
+def test_dump_wal_host_logic(case_name, tmp_path):
+    import wal_dump_cases
+    import wal_dump_util
+    getattr(wal_dump_cases, case_name)(wal_dump_util.dump_with_oracle, str(tmp_path))
