@@ -477,7 +477,16 @@ int run_batch(tcrc_ctx* ctx, BatchParams p, void* stream) {
   int g = ctx->forced_g;
   // Log records are short (a fragment never exceeds 32 KiB, typical ones are a few KiB): four lanes
   // per record halve the end-of-buffer reduction and measured ~9 % faster on 2 KiB records.
-  if (g == 0) g = (p.flags & kFlagWalItems) ? 4 : 8;
+  if (g == 0) {
+    g = (p.flags & kFlagWalItems) ? 4 : 8;
+    // A batch too small to give every wave of the chip eight buffers is latency-bound: spread each
+    // buffer over more lanes instead (a whole wave per buffer when there are fewer buffers than waves).
+    const uint64_t waves = (uint64_t)ctx->cus * 16;
+    if (!p.n_dev) {
+      if (p.n <= waves) g = 64;
+      else if (p.n <= waves * 4) g = 16;
+    }
+  }
   switch (g) {
     case 4: return launch_batch<4>(ctx, p, s);
     case 8: return launch_batch<8>(ctx, p, s);
@@ -562,6 +571,7 @@ int tcrc_shutdown(tcrc_ctx* ctx) {
                           &ctx->long_acc})
     scratch_release(s);
   if (ctx->host_stream) (void)hipStreamDestroy(ctx->host_stream);
+  for (auto& e : ctx->pin_free) (void)hipHostFree(e.first);
   delete ctx;
   return TCRC_OK;
 }

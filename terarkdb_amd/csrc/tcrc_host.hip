@@ -32,15 +32,55 @@ extern "C" {
 
 void* tcrc_host_alloc(tcrc_ctx* ctx, size_t bytes) {
   if (!ctx) return nullptr;
+  if (bytes == 0) bytes = 1;
+  {
+    // smallest kept buffer that is large enough and not more than twice the request
+    std::lock_guard<std::mutex> lock(ctx->pin_mu);
+    size_t best = ctx->pin_free.size();
+    for (size_t i = 0; i < ctx->pin_free.size(); ++i) {
+      const size_t cap = ctx->pin_free[i].second;
+      if (cap >= bytes && cap / 2 <= bytes && (best == ctx->pin_free.size() || cap < ctx->pin_free[best].second))
+        best = i;
+    }
+    if (best != ctx->pin_free.size()) {
+      std::pair<void*, size_t> e = ctx->pin_free[best];
+      ctx->pin_free.erase(ctx->pin_free.begin() + best);
+      ctx->pin_free_bytes -= e.second;
+      ctx->pin_live.push_back(e);
+      return e.first;
+    }
+  }
   if (hipSetDevice(ctx->device) != hipSuccess) return nullptr;
   void* p = nullptr;
-  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+  if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(ctx->pin_mu);
+  ctx->pin_live.emplace_back(p, bytes);
   return p;
 }
 
 void tcrc_host_free(tcrc_ctx* ctx, void* p) {
-  (void)ctx;
-  if (p) (void)hipHostFree(p);
+  if (!p) return;
+  if (!ctx) {
+    (void)hipHostFree(p);
+    return;
+  }
+  const size_t kKeepBytes = (size_t)1 << 30, kKeepCount = 16;
+  size_t cap = 0;
+  {
+    std::lock_guard<std::mutex> lock(ctx->pin_mu);
+    for (size_t i = 0; i < ctx->pin_live.size(); ++i)
+      if (ctx->pin_live[i].first == p) {
+        cap = ctx->pin_live[i].second;
+        ctx->pin_live.erase(ctx->pin_live.begin() + i);
+        break;
+      }
+    if (cap && ctx->pin_free_bytes + cap <= kKeepBytes && ctx->pin_free.size() < kKeepCount) {
+      ctx->pin_free.emplace_back(p, cap);
+      ctx->pin_free_bytes += cap;
+      return;
+    }
+  }
+  (void)hipHostFree(p);
 }
 
 int tcrc_host_batch_stamp(tcrc_ctx* ctx, const void* h_base, uint64_t base_bytes, const tcrc_desc* h_desc, uint64_t n,
@@ -167,6 +207,17 @@ int tcrc_extend(tcrc_ctx* ctx, uint32_t init, const void* h_data, size_t n, uint
   const size_t piece = (size_t)256 << 20;
   if (int rc = scratch_reserve(ctx, &ctx->host_out, 64)) return rc;
   uint32_t crc = init;
+  if (n <= (16u << 10)) {
+    // short input: one wave walks it in a single launch (the segment machinery costs more than it saves)
+    if (int rc = upload(ctx, &ctx->host_data, h_data, n)) return rc;
+    if (int rc = tcrc_dev_blocks_stamp(ctx, ctx->host_data.p, 1, (uint32_t)n, n, init, -1, nullptr, 0,
+                                       (uint32_t*)ctx->host_out.p, ctx->host_stream))
+      return rc;
+    HIP_TRY(hipMemcpyAsync(&crc, ctx->host_out.p, 4, hipMemcpyDeviceToHost, ctx->host_stream));
+    HIP_TRY(hipStreamSynchronize(ctx->host_stream));
+    *out = crc;
+    return TCRC_OK;
+  }
   for (size_t done = 0; done < n;) {
     const size_t len = n - done < piece ? n - done : piece;
     if (int rc = upload(ctx, &ctx->host_data, (const uint8_t*)h_data + done, len)) return rc;

@@ -5,6 +5,8 @@
 
 #include <mutex>
 #include <string>
+#include <utility>
+#include <vector>
 
 #include "../../include/tcrc.h"
 
@@ -83,6 +85,12 @@ struct tcrc_ctx {
   tcrc_scratch long_in, long_desc, long_owner, long_after, long_pow, long_acc;
   uint32_t long_pow_seg = 0;      // segment length the cached power table was built for
   uint32_t long_pow_count = 0;    // entries in it
+  // Pinned host buffers handed back through tcrc_host_free, kept for the next tcrc_host_alloc:
+  // pinning memory costs about as much as copying it, and callers allocate staging per call.
+  std::mutex pin_mu;
+  std::vector<std::pair<void*, size_t>> pin_free;  // (pointer, capacity)
+  std::vector<std::pair<void*, size_t>> pin_live;  // handed out: capacity by pointer
+  size_t pin_free_bytes = 0;
 };
 
 namespace tcrc_internal {

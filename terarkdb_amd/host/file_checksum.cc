@@ -1,7 +1,9 @@
 #include "file_checksum.h"
 
+#include <algorithm>
 #include <limits>
 #include <memory>
+#include <thread>
 
 namespace terarkdb_amd {
 
@@ -41,11 +43,43 @@ Status CalculateChecksum(tcrc_ctx* ctx, SequentialFile* src, uint64_t size_limit
 
 Status CalculateChecksum(tcrc_ctx* ctx, const std::string& src, uint64_t size_limit, uint32_t* checksum_value,
                          uint64_t* size, size_t buffer_size) {
+  // Same value as the sequential loop above; the file is read with positional reads on several
+  // threads into two alternating pinned buffers, so reading buffer k+1 overlaps the engine's work on k.
   *checksum_value = 0;
-  std::unique_ptr<SequentialFile> file;
-  Status s = NewPosixSequentialFile(src, &file);
+  if (size) *size = 0;
+  if (buffer_size == 0) return Status::InvalidArgument("buffer_size must be positive");
+  std::unique_ptr<RandomAccessFile> file;
+  Status s = NewPosixRandomAccessFile(src, &file);
   if (!s.ok()) return s;
-  return CalculateChecksum(ctx, file.get(), size_limit, checksum_value, size, buffer_size);
+  uint64_t total = file->Size();
+  if (size_limit != 0 && size_limit < total) total = size_limit;
+  if (total == 0) return Status::OK();
+  if (buffer_size > total) buffer_size = static_cast<size_t>(total);
+  PinnedBuffer a(ctx, buffer_size), b(ctx, total > buffer_size ? buffer_size : 1);
+  if (!a.p || !b.p) return Status::IOError("checksum engine: cannot allocate the pinned read buffers");
+  char* buf[2] = {a.p, b.p};
+  Status read_status[2];
+  const int kReadThreads = 8;
+  auto piece = [&](uint64_t k) { return static_cast<size_t>(std::min<uint64_t>(buffer_size, total - k * buffer_size)); };
+  const uint64_t pieces = (total + buffer_size - 1) / buffer_size;
+  read_status[0] = ParallelRead(file.get(), 0, piece(0), buf[0], kReadThreads);
+  for (uint64_t k = 0; k < pieces; ++k) {
+    std::thread next;
+    if (k + 1 < pieces) {
+      Status* st = &read_status[(k + 1) & 1];
+      char* dst = buf[(k + 1) & 1];
+      const uint64_t off = (k + 1) * buffer_size;
+      const size_t len = piece(k + 1);
+      const RandomAccessFile* f = file.get();
+      next = std::thread([f, off, len, dst, st] { *st = ParallelRead(f, off, len, dst, kReadThreads); });
+    }
+    s = read_status[k & 1];
+    if (s.ok() && tcrc_extend(ctx, *checksum_value, buf[k & 1], piece(k), checksum_value) != TCRC_OK) s = EngineError();
+    if (s.ok() && size) *size += piece(k);
+    if (next.joinable()) next.join();
+    if (!s.ok()) return s;
+  }
+  return Status::OK();
 }
 
 Status CopyOrCreateFile(tcrc_ctx* ctx, const std::string& src, const std::string& dst, const std::string& contents,

@@ -1,5 +1,8 @@
 #include "files.h"
 
+#include <thread>
+#include <vector>
+
 #include <errno.h>
 #include <fcntl.h>
 #include <stdio.h>
@@ -210,6 +213,42 @@ Status MemRandomAccessFile::Read(uint64_t offset, size_t n, Slice* result, char*
   if (k > n) k = n;
   memcpy(scratch, c.data() + offset, k);
   *result = Slice(scratch, k);
+  return Status::OK();
+}
+
+Status ParallelRead(const RandomAccessFile* file, uint64_t offset, size_t n, char* buf, int threads) {
+  const size_t kMinPerThread = 4u << 20;
+  int t = threads < 1 ? 1 : threads;
+  if (n / kMinPerThread < static_cast<size_t>(t)) t = static_cast<int>(n / kMinPerThread) + 1;
+  std::vector<Status> st(t);
+  auto work = [&](int k) {
+    const size_t lo = n * k / t, hi = n * (k + 1) / t;
+    size_t done = lo;
+    while (done < hi) {
+      Slice got;
+      Status s = file->Read(offset + done, hi - done, &got, buf + done);
+      if (!s.ok()) {
+        st[k] = s;
+        return;
+      }
+      if (got.size() == 0) {
+        st[k] = Status::IOError("unexpected end of file");
+        return;
+      }
+      if (got.data() != buf + done) memcpy(buf + done, got.data(), got.size());
+      done += got.size();
+    }
+  };
+  if (t == 1) {
+    work(0);
+  } else {
+    std::vector<std::thread> pool;
+    for (int k = 1; k < t; ++k) pool.emplace_back(work, k);
+    work(0);
+    for (auto& th : pool) th.join();
+  }
+  for (const Status& s : st)
+    if (!s.ok()) return s;
   return Status::OK();
 }
 

@@ -42,6 +42,10 @@ Status NewPosixSequentialFile(const std::string& path, std::unique_ptr<Sequentia
 Status NewPosixRandomAccessFile(const std::string& path, std::unique_ptr<RandomAccessFile>* out);
 Status NewPosixWritableFile(const std::string& path, std::unique_ptr<WritableFile>* out);
 
+// Fills buf with file bytes [offset, offset + n) using up to `threads` concurrent positional reads
+// (page-cache copies are memcpy-bound per thread).  Fails if the file ends before offset + n.
+Status ParallelRead(const RandomAccessFile* file, uint64_t offset, size_t n, char* buf, int threads);
+
 // ---- in-memory fakes ---------------------------------------------------------------
 
 // The bytes of one in-memory file, shared by a sink (writer side) and any number of sources.

@@ -169,126 +169,105 @@ Status CheckPacked(const Run& r, std::vector<Item>* items, std::vector<std::stri
   return Status::OK();
 }
 
-// Fills buf with file bytes [offset, offset + n) using several pread streams.
-Status ParallelRead(const RandomAccessFile* file, uint64_t offset, size_t n, char* buf, int threads) {
-  const size_t kMinPerThread = 4u << 20;
-  int t = threads < 1 ? 1 : threads;
-  if (n / kMinPerThread < static_cast<size_t>(t)) t = static_cast<int>(n / kMinPerThread) + 1;
-  std::vector<Status> st(t);
-  auto work = [&](int k) {
-    const size_t lo = n * k / t, hi = n * (k + 1) / t;
-    size_t done = lo;
-    while (done < hi) {
-      Slice got;
-      Status s = file->Read(offset + done, hi - done, &got, buf + done);
-      if (!s.ok()) {
-        st[k] = s;
-        return;
-      }
-      if (got.size() == 0) {
-        st[k] = Status::IOError("unexpected end of file");
-        return;
-      }
-      if (got.data() != buf + done) memcpy(buf + done, got.data(), got.size());
-      done += got.size();
-    }
-  };
-  if (t == 1) {
-    work(0);
-  } else {
-    std::vector<std::thread> pool;
-    for (int k = 1; k < t; ++k) pool.emplace_back(work, k);
-    work(0);
-    for (auto& th : pool) th.join();
-  }
-  for (const Status& s : st)
-    if (!s.ok()) return s;
-  return Status::OK();
-}
-
 // Data blocks: runs of handles that lie within extent_bytes of each other are read with one
-// large read and checked with one engine call.
-Status CheckExtents(const Run& r, std::vector<Item>* items) {
-  const size_t n = items->size();
-  size_t cap = 0;
-  char* stage = nullptr;
-  Status result;
+// large read and checked with one engine call.  Two staging buffers alternate, so the file read
+// of the next extent runs while the engine works on the current one.
+struct Extent {
+  uint64_t lo = 0;
+  size_t bytes = 0;
   std::vector<tcrc_desc> spans;
   std::vector<size_t> which;
-  std::vector<uint32_t> computed;
-  std::vector<uint8_t> ok;
-  size_t i = 0;
-  while (i < n && result.ok()) {
-    // skip blocks that cannot be read at all
+};
+
+Status CheckExtents(const Run& r, std::vector<Item>* items) {
+  const size_t n = items->size();
+  // plan
+  std::vector<Extent> extents;
+  for (size_t i = 0; i < n;) {
     Item& first = (*items)[i];
     first.status = BoundsStatus(first.handle, r.file_size, r.file_name);
-    if (!first.status.ok()) {
-      ++i;
-      continue;
-    }
-    if (first.handle.size + 1 >= 0xffffffffull) {
+    if (first.status.ok() && first.handle.size + 1 >= 0xffffffffull)
       first.status = Status::NotSupported("block of 4 GiB or more");
+    if (!first.status.ok()) {  // cannot be read at all: reported in order later
       ++i;
       continue;
     }
-    const uint64_t lo = first.handle.offset;
-    uint64_t hi = lo + first.handle.size + kBlockTrailerSize;
-    spans.clear();
-    which.clear();
+    Extent e;
+    e.lo = first.handle.offset;
+    uint64_t hi = e.lo + first.handle.size + kBlockTrailerSize;
     size_t j = i;
     for (; j < n; ++j) {
       Item& it = (*items)[j];
       if (j > i) {
         it.status = BoundsStatus(it.handle, r.file_size, r.file_name);
-        if (!it.status.ok()) continue;  // reported in order later; does not break the run
-        if (it.handle.size + 1 >= 0xffffffffull) {
+        if (it.status.ok() && it.handle.size + 1 >= 0xffffffffull)
           it.status = Status::NotSupported("block of 4 GiB or more");
-          continue;
-        }
+        if (!it.status.ok()) continue;  // does not break the run
         const uint64_t end = it.handle.offset + it.handle.size + kBlockTrailerSize;
-        if (it.handle.offset < lo || std::max(end, hi) - lo > r.options.extent_bytes) break;
+        if (it.handle.offset < e.lo || std::max(end, hi) - e.lo > r.options.extent_bytes) break;
         hi = std::max(hi, end);
       }
       tcrc_desc d;
-      d.offset = it.handle.offset - lo;
+      d.offset = it.handle.offset - e.lo;
       d.len = static_cast<uint32_t>(it.handle.size + 1);
       d.init = 0;
-      spans.push_back(d);
-      which.push_back(j);
+      e.spans.push_back(d);
+      e.which.push_back(j);
     }
-    const size_t bytes = static_cast<size_t>(hi - lo);
-    if (r.checksum == kCRC32c) {
-      if (bytes > cap) {
-        if (stage) r.checker->FreeStaging(stage);
-        cap = std::max(bytes, std::min<size_t>(r.options.extent_bytes, static_cast<size_t>(r.file_size)));
-        stage = r.checker->AllocStaging(cap);
-        if (!stage) {
-          result = Status::IOError("cannot allocate the staging buffer for a file extent");
-          break;
-        }
-      }
-      result = ParallelRead(r.file, lo, bytes, stage, r.options.read_threads);
-      if (!result.ok()) break;
-      computed.resize(spans.size());
-      ok.resize(spans.size());
-      result = r.checker->Check(stage, bytes, spans.data(), spans.size(), computed.data(), ok.data());
-      if (!result.ok()) break;
-      if (r.stats) ++r.stats->engine_calls;
-      for (size_t k = 0; k < spans.size(); ++k) {
-        Item& it = (*items)[which[k]];
-        it.checked = true;
-        if (r.stats) r.stats->bytes_covered += spans[k].len;
-        if (ok[k]) continue;
-        if (r.stats) ++r.stats->mismatches;
-        const uint32_t stored = DecodeFixed32(stage + spans[k].offset + spans[k].len);
-        it.status = MismatchStatus(computed[k], stored, r.file_name, it.handle);
-      }
-    } else if (r.checksum != kNoChecksum) {
-      for (size_t k : which) (*items)[k].status = UnknownChecksumStatus(r, (*items)[k].handle);
-    }
+    e.bytes = static_cast<size_t>(hi - e.lo);
+    extents.push_back(std::move(e));
     i = j;
   }
-  if (stage) r.checker->FreeStaging(stage);
+  if (r.checksum == kNoChecksum || extents.empty()) return Status::OK();
+  if (r.checksum != kCRC32c) {
+    for (const Extent& e : extents)
+      for (size_t k : e.which) (*items)[k].status = UnknownChecksumStatus(r, (*items)[k].handle);
+    return Status::OK();
+  }
+  size_t cap = 0;
+  for (const Extent& e : extents) cap = std::max(cap, e.bytes);
+  char* stage[2] = {r.checker->AllocStaging(cap), extents.size() > 1 ? r.checker->AllocStaging(cap) : nullptr};
+  if (!stage[0] || (extents.size() > 1 && !stage[1])) {
+    if (stage[0]) r.checker->FreeStaging(stage[0]);
+    if (stage[1]) r.checker->FreeStaging(stage[1]);
+    return Status::IOError("cannot allocate the staging buffers for file extents");
+  }
+  Status result, read_status[2];
+  std::vector<uint32_t> computed;
+  std::vector<uint8_t> ok;
+  read_status[0] = ParallelRead(r.file, extents[0].lo, extents[0].bytes, stage[0], r.options.read_threads);
+  for (size_t x = 0; x < extents.size() && result.ok(); ++x) {
+    const Extent& e = extents[x];
+    char* cur = stage[x & 1];
+    std::thread next;
+    if (x + 1 < extents.size()) {
+      const Extent* ne = &extents[x + 1];
+      Status* st = &read_status[(x + 1) & 1];
+      char* dst = stage[(x + 1) & 1];
+      next = std::thread([&r, ne, st, dst] { *st = ParallelRead(r.file, ne->lo, ne->bytes, dst, r.options.read_threads); });
+    }
+    result = read_status[x & 1];
+    if (result.ok()) {
+      computed.resize(e.spans.size());
+      ok.resize(e.spans.size());
+      result = r.checker->Check(cur, e.bytes, e.spans.data(), e.spans.size(), computed.data(), ok.data());
+    }
+    if (result.ok()) {
+      if (r.stats) ++r.stats->engine_calls;
+      for (size_t k = 0; k < e.spans.size(); ++k) {
+        Item& it = (*items)[e.which[k]];
+        it.checked = true;
+        if (r.stats) r.stats->bytes_covered += e.spans[k].len;
+        if (ok[k]) continue;
+        if (r.stats) ++r.stats->mismatches;
+        const uint32_t stored = DecodeFixed32(cur + e.spans[k].offset + e.spans[k].len);
+        it.status = MismatchStatus(computed[k], stored, r.file_name, it.handle);
+      }
+    }
+    if (next.joinable()) next.join();
+  }
+  r.checker->FreeStaging(stage[0]);
+  if (stage[1]) r.checker->FreeStaging(stage[1]);
   return result;
 }
 

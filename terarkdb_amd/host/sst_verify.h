@@ -101,7 +101,7 @@ class DeviceBlockBatchChecker : public BlockBatchChecker {
 
 struct SstVerifyOptions {
   // Data blocks are read and submitted in runs of up to this many file bytes.
-  size_t extent_bytes = 256u << 20;
+  size_t extent_bytes = 64u << 20;
   // Threads that pread one extent into the pinned staging buffer.
   int read_threads = 8;
   // BlockBasedTableOptions::index_type to assume when the file's properties do not name one

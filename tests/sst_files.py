@@ -254,3 +254,68 @@ def flip(path, offset, bit=0):
         b = fh.read(1)[0]
         fh.seek(offset)
         fh.write(bytes([b ^ (1 << bit)]))
+
+
+def build_uniform_table(path, n_data, block_len=8192, seed_state=301, index="binary"):
+    """A large table written fast: data blocks are block_len bytes of the splitmix64 stream (verification
+    never parses data blocks), trailers from the oracle's batch path; index, properties, metaindex and
+    footer as in build_table.  Returns the Layout (order lists only the first/last few data blocks)."""
+    lay = Layout(path)
+    stride = block_len + TRAILER
+    body = O.splitmix(n_data * block_len, seed_state).reshape(n_data, block_len)
+    crcs = O.sst_trailer_batch(body, block_len, block_len, n_data, 0, hw=True)
+    img = np.zeros((n_data, stride), dtype=np.uint8)
+    img[:, :block_len] = body
+    img[:, block_len + 1:] = crcs.astype("<u4").view(np.uint8).reshape(n_data, 4)
+    out = bytearray(img.tobytes())
+    del img, body
+
+    def write_raw(role, contents):
+        off = len(out)
+        out.extend(contents)
+        out.extend(_trailer(contents, 0, 1))
+        lay.blocks[role] = (off, len(contents))
+        return off, len(contents)
+
+    handles = [(b * stride, block_len) for b in range(n_data)]
+    keys = [b"key%010d" % b + b"\x01\0\0\0\0\0\0\0" for b in range(n_data)]
+
+    def index_block(ks, hs):
+        bb = BlockBuilder(1)
+        for k, (o, s) in zip(ks, hs):
+            bb.add(k, handle_bytes(o, s))
+        return bb.finish()
+
+    n_index = 1
+    if index == "two_level":
+        per = 256
+        ph, pk = [], []
+        for p0 in range(0, n_data, per):
+            p1 = min(n_data, p0 + per)
+            ph.append(write_raw("partition%d" % len(ph), index_block(keys[p0:p1], handles[p0:p1])))
+            pk.append(keys[p1 - 1])
+        index_handle = write_raw("index", index_block(pk, ph))
+        n_index += len(ph)
+    else:
+        index_handle = write_raw("index", index_block(keys, handles))
+    props = {
+        b"rocksdb.block.based.table.index.type": struct.pack("<I", 2 if index == "two_level" else 0),
+        b"rocksdb.num.data.blocks": varint(n_data),
+        b"rocksdb.index.value.is.delta.encoded": varint(0),
+    }
+    bb = BlockBuilder(1)
+    for k in sorted(props):
+        bb.add(k, props[k])
+    ph_ = write_raw("properties", bb.finish())
+    bb = BlockBuilder(1)
+    bb.add(b"rocksdb.properties", handle_bytes(*ph_))
+    mh = write_raw("metaindex", bb.finish())
+    f = bytes([1]) + handle_bytes(*mh) + handle_bytes(*index_handle)
+    f += bytes(41 - len(f)) + struct.pack("<I", 2) + struct.pack("<II", MAGIC & 0xffffffff, MAGIC >> 32)
+    out.extend(f)
+    with open(path, "wb") as fh:
+        fh.write(out)
+    lay.file_size = len(out)
+    lay.n_meta, lay.n_index, lay.n_data = 2, n_index, n_data
+    lay.data_handles = handles
+    return lay

@@ -13,6 +13,7 @@ timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE -d $O/write -o wr -- python3 benc
 python3 tools/rocprof_summary.py kernel $O/kt/kt_results.db $O/bench_kernel_stats.csv > /dev/null
 python3 tools/rocprof_summary.py pmc $O/fetch/fetch_results.db $O/write/wr_results.db k_crc_batch $O/hbm_traffic.json > /dev/null
 timeout -k 10 900 python3 -u tools/measure_paths.py $O/paths.json > $O/paths.log 2>&1
+timeout -k 10 600 python3 -u tools/measure_files.py $O/files.json > $O/files.log 2>&1
 rm -rf $O/kt $O/fetch $O/write
 cat $O/bench.json
 head -4 $O/bench_kernel_stats.csv
