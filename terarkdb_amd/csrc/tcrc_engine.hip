@@ -94,6 +94,7 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p) {
   __shared__ uint32_t lds[kMainDwords + kAuxDwords];
 
   const int tid = threadIdx.x;
+  if (p.n_dev && *p.n_dev == 0) return;  // an empty list (uniform over the grid): nothing to set up
   for (int i = tid; i < kMainDwords; i += kThreads) lds[i] = p.tab_main[i >> 5];
   for (int i = tid; i < kAuxDwords; i += kThreads) lds[kMainDwords + i] = p.tab_aux[i];
   __syncthreads();
@@ -475,6 +476,7 @@ int run_batch(tcrc_ctx* ctx, BatchParams p, void* stream) {
   HIP_TRY(hipSetDevice(ctx->device));
   hipStream_t s = (hipStream_t)stream;
   int g = ctx->forced_g;
+  if (p.lanes) g = p.lanes;  // the caller knows the shape of its spans (log scans)
   // Log records are short (a fragment never exceeds 32 KiB, typical ones are a few KiB): four lanes
   // per record halve the end-of-buffer reduction and measured ~9 % faster on 2 KiB records.
   if (g == 0) {

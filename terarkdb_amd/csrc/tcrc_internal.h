@@ -38,6 +38,7 @@ struct BatchParams {
   const uint32_t* seg_owner;        // kFlagSegments: output slot (buffer index) of every segment
   const uint32_t* seg_after;        // kFlagSegments: number of whole segments that follow it in its buffer
   const uint32_t* seg_pow;          // kFlagSegments: seg_pow[q] = x^(8 * segment_len * q) mod P
+  int lanes;                 // lanes per buffer to use (4, 8, 16, 64), 0 = let the engine choose
   const uint32_t* tab_main;  // 1024 dwords: Z_D set
   const uint32_t* tab_aux;   // (1+log2 G) sets of 1024 dwords: Z_4, Z_16, Z_32, ...
 };

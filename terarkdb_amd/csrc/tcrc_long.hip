@@ -147,6 +147,7 @@ extern "C" int tcrc_dev_extend_long(tcrc_ctx* ctx, const void* d_base, const tcr
   p.n = nseg;
   p.uniform_suffix = -1;
   p.flags = kFlagSegments;
+  p.lanes = 8;  // eight segments per wave are folded before one atomic: wider groups would queue on the accumulator
   p.out = (uint32_t*)ctx->long_acc.p;
   p.seg_owner = e.owner;
   p.seg_after = e.after;

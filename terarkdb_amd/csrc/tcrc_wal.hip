@@ -4,16 +4,16 @@
 // boundary (db/log_writer.cc:58-80), so every block can be parsed on its own.  The
 // scan follows db/log_reader.cc:314-406 (ReadPhysicalRecord) for a complete image
 // read without retries:
-//   1. k_wal_walk<false>: one thread per block walks the headers and counts the
-//      records that pass every structural check (header fits, log number matches,
-//      length fits in the block, not a zero-length zero-type filler);
-//   2. k_scan_counts: exclusive prefix sum of the counts;
-//   3. k_wal_walk<true>: the same walk, now writing one descriptor per record: the
-//      CRC-covered span starts at header+6 (type byte) and runs header_size-6+length
-//      bytes (db/log_reader.cc:389);
-//   4. the batch CRC kernel checks every span against Unmask(fixed32(header))
-//      (db/log_reader.cc:388-390) and keeps, per block, the smallest failing record
-//      index: the reference drops the rest of a block at its first bad checksum
+//   1. k_wal_walk: one thread per block walks the headers and counts the records that
+//      pass every structural check (header fits, log number matches, length fits in
+//      the block, not a zero-length zero-type filler), takes descriptor slots for them
+//      and walks again writing one descriptor per record: the CRC-covered span starts
+//      at header+6 (type byte) and runs header_size-6+length bytes
+//      (db/log_reader.cc:389).  Records of 4 KiB and more go to a second list;
+//   2. the batch CRC kernel checks every span against Unmask(fixed32(header))
+//      (db/log_reader.cc:388-390), four lanes per short record and a whole wave per
+//      long one, and keeps, per block, the smallest failing record index: the
+//      reference drops the rest of a block at its first bad checksum
 //      (db/log_reader.cc:391-397), so that index is all the policy code needs.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -29,17 +29,23 @@ namespace {
 constexpr uint32_t kLogBlock = 32768;  // db/log_format.h:37
 constexpr uint32_t kHeader = 7;        // db/log_format.h:40
 constexpr uint32_t kRecyclableHeader = 11;  // db/log_format.h:44
+// Spans at least this long are checked by a whole wave each: with four lanes a 32 KiB fragment
+// takes ~160 us, which a log of large records (few, long spans) cannot hide behind other work.
+constexpr uint32_t kLongSpan = 4096;
 
 struct WalkParams {
   const uint8_t* img;
   uint64_t size;        // bytes in this image (the last block may be short)
   uint64_t log_number;
   uint32_t nblocks;
-  tcrc_desc* items;
+  tcrc_desc* items;  // short spans
   uint32_t* item_block;
   uint64_t capacity;
+  tcrc_desc* items_long;  // spans of kLongSpan bytes and more
+  uint32_t* item_block_long;
+  uint64_t capacity_long;
   tcrc_wal_block* blocks;       // [nblocks] n_records / first_bad / end_offset / end_code
-  unsigned long long* n_items;  // running total of descriptors handed out
+  unsigned long long* n_items;  // [2] running totals of short / long descriptors handed out
 };
 
 // One header step of db/log_reader.cc:317-384.  Returns false when the walk of the block ends
@@ -82,49 +88,68 @@ __device__ __forceinline__ bool wal_step(const uint8_t* img, uint64_t pos, uint6
   return true;
 }
 
-// One thread per 32 KiB block.  Pass 1 counts the block's records; the 64 counts of a wave are
-// prefix-summed with shuffles and the wave takes its run of descriptor slots with ONE atomic add;
-// pass 2 walks the (now cached) headers again and writes the descriptors.  Descriptors of one block
-// are contiguous, blocks land in no particular order - nothing downstream depends on it.
+__device__ __forceinline__ uint32_t wave_exclusive_sum(uint32_t v, uint32_t lane, uint32_t* total) {
+  uint32_t incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t up = __shfl_up(incl, d);
+    if ((int)lane >= d) incl += up;
+  }
+  *total = __shfl(incl, 63);
+  return incl - v;
+}
+
+// One thread per 32 KiB block.  Pass 1 counts the block's short and long records; the 64 counts of a
+// wave are prefix-summed with shuffles and the wave takes its runs of descriptor slots with ONE atomic
+// add per list; pass 2 walks the (now cached) headers again and writes the descriptors.  Descriptors
+// of one block are contiguous within a list, blocks land in no particular order - nothing downstream
+// depends on it.
 __global__ __launch_bounds__(256) void k_wal_walk(WalkParams p) {
   const uint32_t blk = blockIdx.x * 256u + threadIdx.x;
   const bool have = blk < p.nblocks;
   const uint64_t base = (uint64_t)blk * kLogBlock;
   const uint64_t end = base + kLogBlock < p.size ? base + kLogBlock : p.size;
   const bool last = end == p.size;
-  uint32_t n = 0, code = TCRC_WAL_END_CLEAN, hs = 0, len = 0;
+  uint32_t n = 0, n_long = 0, code = TCRC_WAL_END_CLEAN, hs = 0, len = 0;
   uint64_t pos = base;
   if (have) {
     while (wal_step(p.img, pos, end, last, p.log_number, &hs, &len, &code)) {
       ++n;
+      if (len + hs - 6 >= kLongSpan) ++n_long;
       pos += hs + len;
     }
   }
   const uint32_t lane = threadIdx.x & 63u;
-  uint32_t incl = n;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint32_t up = __shfl_up(incl, d);
-    if ((int)lane >= d) incl += up;
-  }
-  const uint32_t wave_total = __shfl(incl, 63);
-  unsigned long long wave_base = 0;
-  if (lane == 63u && wave_total) wave_base = atomicAdd(p.n_items, (unsigned long long)wave_total);
-  wave_base = __shfl(wave_base, 63);
+  uint32_t total_s, total_l;
+  const uint32_t excl_s = wave_exclusive_sum(n - n_long, lane, &total_s);
+  const uint32_t excl_l = wave_exclusive_sum(n_long, lane, &total_l);
+  unsigned long long base_s = 0, base_l = 0;
+  if (lane == 63u && total_s) base_s = atomicAdd(&p.n_items[0], (unsigned long long)total_s);
+  if (lane == 63u && total_l) base_l = atomicAdd(&p.n_items[1], (unsigned long long)total_l);
+  base_s = __shfl(base_s, 63);
+  base_l = __shfl(base_l, 63);
   if (!have) return;
-  const uint64_t slot0 = wave_base + incl - n;
+  uint64_t slot_s = base_s + excl_s, slot_l = base_l + excl_l;
   uint64_t q = base;
   for (uint32_t k = 0; k < n; ++k) {
     uint32_t c2;
     wal_step(p.img, q, end, last, p.log_number, &hs, &len, &c2);
-    const uint64_t slot = slot0 + k;
-    if (slot < p.capacity) {
-      tcrc_desc d;
-      d.offset = q + 6;  // the CRC covers the type byte, the log number if any, and the payload
-      d.len = len + hs - 6;
-      d.init = k;
-      p.items[slot] = d;
-      p.item_block[slot] = blk;
+    tcrc_desc d;
+    d.offset = q + 6;  // the CRC covers the type byte, the log number if any, and the payload
+    d.len = len + hs - 6;
+    d.init = k;
+    if (d.len >= kLongSpan) {
+      if (slot_l < p.capacity_long) {
+        p.items_long[slot_l] = d;
+        p.item_block_long[slot_l] = blk;
+      }
+      ++slot_l;
+    } else {
+      if (slot_s < p.capacity) {
+        p.items[slot_s] = d;
+        p.item_block[slot_s] = blk;
+      }
+      ++slot_s;
     }
     q += hs + len;
   }
@@ -136,7 +161,7 @@ __global__ __launch_bounds__(256) void k_wal_walk(WalkParams p) {
   p.blocks[blk] = r;
 }
 
-// misc: [0] descriptors wanted, [1] unused, [2..4] TCRC_CNT_* of this slice.  The slice's counters
+// misc: [0] short descriptors wanted, [1] long ones, [2..4] TCRC_CNT_* of this slice.  The slice's counters
 // reach the caller's block only if every descriptor fitted (otherwise the slice is redone).
 __global__ void k_wal_init(unsigned long long* misc) {
   misc[0] = 0ull;
@@ -146,8 +171,9 @@ __global__ void k_wal_init(unsigned long long* misc) {
   misc[2 + TCRC_CNT_CHECKED] = 0ull;
 }
 
-__global__ void k_wal_finish(const unsigned long long* misc, unsigned long long capacity, unsigned long long* counts) {
-  if (misc[0] > capacity) return;
+__global__ void k_wal_finish(const unsigned long long* misc, unsigned long long capacity,
+                             unsigned long long capacity_long, unsigned long long* counts) {
+  if (misc[0] > capacity || misc[1] > capacity_long) return;
   atomicAdd(&counts[TCRC_CNT_MISMATCH], misc[2 + TCRC_CNT_MISMATCH]);
   atomicMin(&counts[TCRC_CNT_FIRST_BAD], misc[2 + TCRC_CNT_FIRST_BAD]);
   atomicAdd(&counts[TCRC_CNT_CHECKED], misc[2 + TCRC_CNT_CHECKED]);
@@ -173,12 +199,14 @@ extern "C" int tcrc_dev_wal_verify(tcrc_ctx* ctx, const void* d_img, uint64_t si
     const uint32_t nb = (uint32_t)(nblocks_total - b0 < slice_blocks ? nblocks_total - b0 : slice_blocks);
     const uint64_t off = b0 * kLogBlock;
     const uint64_t bytes = size - off < (uint64_t)nb * kLogBlock ? size - off : (uint64_t)nb * kLogBlock;
-    // Descriptor room for one record per 32 bytes; a log made of smaller records is redone once
-    // with the exact count the first attempt reports.
-    uint64_t capacity = bytes / 32 + 1024;
+    // Descriptor room for one short record per 32 bytes and one long one per kLongSpan bytes; a log
+    // made of smaller records is redone once with the exact counts the first attempt reports.
+    uint64_t capacity = bytes / 32 + 1024, capacity_long = bytes / kLongSpan + 1024;
     for (int attempt = 0;; ++attempt) {
-      if (int rc = scratch_reserve(ctx, &ctx->wal_items, capacity * sizeof(tcrc_desc))) return rc;
-      if (int rc = scratch_reserve(ctx, &ctx->wal_item_block, capacity * 4)) return rc;
+      const size_t long_off = (capacity * sizeof(tcrc_desc) + 255) & ~(size_t)255;
+      const size_t long_off_b = (capacity * 4 + 255) & ~(size_t)255;
+      if (int rc = scratch_reserve(ctx, &ctx->wal_items, long_off + capacity_long * sizeof(tcrc_desc))) return rc;
+      if (int rc = scratch_reserve(ctx, &ctx->wal_item_block, long_off_b + capacity_long * 4)) return rc;
       if (int rc = scratch_reserve(ctx, &ctx->wal_misc, 64)) return rc;
       unsigned long long* misc = (unsigned long long*)ctx->wal_misc.p;
       WalkParams w{};
@@ -189,6 +217,9 @@ extern "C" int tcrc_dev_wal_verify(tcrc_ctx* ctx, const void* d_img, uint64_t si
       w.items = (tcrc_desc*)ctx->wal_items.p;
       w.item_block = (uint32_t*)ctx->wal_item_block.p;
       w.capacity = capacity;
+      w.items_long = (tcrc_desc*)((uint8_t*)ctx->wal_items.p + long_off);
+      w.item_block_long = (uint32_t*)((uint8_t*)ctx->wal_item_block.p + long_off_b);
+      w.capacity_long = capacity_long;
       w.blocks = d_blocks + b0;
       w.n_items = misc;
       hipLaunchKernelGGL(k_wal_init, dim3(1), dim3(1), 0, s, misc);
@@ -196,29 +227,39 @@ extern "C" int tcrc_dev_wal_verify(tcrc_ctx* ctx, const void* d_img, uint64_t si
       HIP_TRY(hipGetLastError());
       BatchParams p{};
       p.base = w.img;
-      p.desc = w.items;
-      p.n = capacity;
-      p.n_dev = misc;  // the kernel takes min(capacity, descriptors written)
       p.uniform_suffix = -1;
       p.flags = TCRC_F_MASK | TCRC_F_EXPECT_BEFORE | kFlagWalItems;
       p.verify = 1;
       p.counts = misc + 2;
-      p.item_block = w.item_block;
       p.wal_blocks = w.blocks;
       p.wal_block_base = b0;
+      // short spans: four lanes each; the kernel takes min(capacity, descriptors written)
+      p.desc = w.items;
+      p.n = capacity;
+      p.n_dev = misc;
+      p.item_block = w.item_block;
+      p.lanes = 4;
+      if (int rc = run_batch(ctx, p, stream)) return rc;
+      // long spans: a wave each
+      p.desc = w.items_long;
+      p.n = capacity_long;
+      p.n_dev = misc + 1;
+      p.item_block = w.item_block_long;
+      p.lanes = 64;
       if (int rc = run_batch(ctx, p, stream)) return rc;
       hipLaunchKernelGGL(k_wal_finish, dim3(1), dim3(1), 0, s, misc, (unsigned long long)capacity,
-                         (unsigned long long*)d_counts);
+                         (unsigned long long)capacity_long, (unsigned long long*)d_counts);
       HIP_TRY(hipGetLastError());
-      unsigned long long wanted = 0;
-      HIP_TRY(hipMemcpyAsync(&wanted, misc, 8, hipMemcpyDeviceToHost, s));
+      unsigned long long wanted[2] = {0, 0};
+      HIP_TRY(hipMemcpyAsync(wanted, misc, 16, hipMemcpyDeviceToHost, s));
       HIP_TRY(hipStreamSynchronize(s));
-      if (wanted <= capacity) {
-        total_records += wanted;
+      if (wanted[0] <= capacity && wanted[1] <= capacity_long) {
+        total_records += wanted[0] + wanted[1];
         break;
       }
       if (attempt) return fail(TCRC_ERR_HIP, "log scan: descriptor count changed between passes");
-      capacity = wanted;
+      capacity = wanted[0] > capacity ? wanted[0] : capacity;
+      capacity_long = wanted[1] > capacity_long ? wanted[1] : capacity_long;
     }
   }
   if (h_records) *h_records = total_records;
