@@ -10,8 +10,8 @@ the stored trailer value.  Inputs are resident in HBM before the timed region.
         --master-port P bench.py --gpus N --steps K --warmup W
 
 With N > 1 every rank owns one GPU and one 1 GiB shard of the corpus (block-range sharding,
-weak scaling); no data moves between GPUs, and the only collective is one all-reduce (RCCL)
-of {mismatches, blocks checked} inside the timed region.
+weak scaling); no data moves between GPUs, and the only collective is one 24-byte all-gather (RCCL)
+of {mismatches, blocks checked, first bad block} inside the timed region.
 
 Rank 0 prints ONE JSON line.
 """
@@ -99,7 +99,8 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dist = None
-    if world > 1:
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:
+        # under torchrun the process group is used even with one rank, so the same code path runs at every N
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -174,7 +175,7 @@ def main():
     ev_end.record()
     c = counts.cpu().numpy().view(np.uint64)  # waits for the K launches
     fb_local = int(c[capi.CNT_FIRST_BAD])
-    # the path's only exchange: {mismatches, checked} summed and the first bad block min-ed over ranks (RCCL)
+    # the path's only exchange: every rank's {mismatches, checked, first bad block}, one all-gather (RCCL)
     totals = allreduce_totals(int(c[capi.CNT_MISMATCH]), int(c[capi.CNT_CHECKED]),
                               None if fb_local == 2**64 - 1 else fb_local, rank * N_BLOCKS,
                               device="cuda" if dist else None)
@@ -216,7 +217,7 @@ def main():
             "config": {"workload": "1 GiB batch of 8 KiB SST data blocks per GPU (131072 blocks, type byte 0): "
                                    "masked CRC32C stamped and verified against stored trailers",
                        "settle_seconds_untimed": args.settle_seconds, "block_len": BLOCK_LEN, "blocks_per_gpu": N_BLOCKS, "sharding": "block range per GPU",
-                       "collective": "one all-reduce of {mismatches, checked}" if world > 1 else "none"},
+                       "collective": "one all-gather of {mismatches, checked, first_bad} (24 B per rank)" if dist else "none"},
             "pct_hbm_peak": round(100.0 * value / (HBM_PEAK_GBS * world), 2),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

@@ -2,7 +2,7 @@
 
 Every SST block and every 32 KiB log block carries its own checksum, so a corpus splits
 into contiguous ranges that are verified independently, one process per GPU.  No data
-moves between GPUs; the only exchange is one all-reduce of a few counters
+moves between GPUs; the only exchange is one all-gather of three counters per rank
 (`torch.distributed`: RCCL over xGMI with the "nccl" backend, gloo on CPUs).
 """
 from dataclasses import dataclass
@@ -36,10 +36,15 @@ def allreduce_totals(mismatches, checked, first_bad_local, shard_lo, device=None
     fb = NO_BAD
     if first_bad_local is not None and 0 <= int(first_bad_local) < NO_BAD:
         fb = shard_lo + int(first_bad_local)
-    sums = torch.tensor([int(mismatches), int(checked)], dtype=torch.int64, device=device)
-    mins = torch.tensor([fb], dtype=torch.int64, device=device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
-        dist.all_reduce(mins, op=dist.ReduceOp.MIN)
-    first = int(mins[0].item())
-    return VerifyTotals(int(sums[0].item()), int(sums[1].item()), -1 if first == NO_BAD else first)
+    mine = torch.tensor([int(mismatches), int(checked), fb], dtype=torch.int64, device=device)
+    if dist.is_available() and dist.is_initialized():
+        # one collective: every rank's three counters, summed / min-ed locally (a sum and a min
+        # would otherwise need two all-reduces)
+        world = dist.get_world_size()
+        everyone = torch.empty(3 * world, dtype=torch.int64, device=device)
+        dist.all_gather_into_tensor(everyone, mine)
+        rows = everyone.view(world, 3).cpu()
+    else:
+        rows = mine.view(1, 3).cpu()
+    first = int(rows[:, 2].min().item())
+    return VerifyTotals(int(rows[:, 0].sum().item()), int(rows[:, 1].sum().item()), -1 if first == NO_BAD else first)

@@ -1,4 +1,4 @@
-"""The multi-GPU path's host logic on CPUs: two processes (gloo), block-range shards, one all-reduce
+"""The multi-GPU path's host logic on CPUs: two processes (gloo), block-range shards, one collective
 of the verify counters.  Per-shard verification is done by the CPU oracle here (the GPU engine takes
 its place on GPUs; bench.py --gpus N runs that)."""
 import os
