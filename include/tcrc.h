@@ -136,6 +136,27 @@ typedef struct tcrc_wal_block {
 int tcrc_dev_wal_verify(tcrc_ctx* ctx, const void* d_img, uint64_t size, uint64_t log_number, tcrc_wal_block* d_blocks,
                         uint64_t* d_counts, uint64_t* h_records, void* stream);
 
+/* One physical record of a log image, as ReadPhysicalRecord would meet it. */
+#define TCRC_WAL_REC_BAD 0     /* checksum mismatch: the reference drops the rest of the block here */
+#define TCRC_WAL_REC_OK 1      /* checksum matches and no earlier record of the block failed */
+#define TCRC_WAL_REC_SKIPPED 2 /* lies after a bad record of the same block: never examined by the reference */
+typedef struct tcrc_wal_record {
+  uint64_t offset;      /* of the record header in the image */
+  uint32_t length;      /* payload bytes (the header's length field) */
+  uint8_t type;         /* record type byte (db/log_format.h:19-35) */
+  uint8_t status;       /* TCRC_WAL_REC_* */
+  uint16_t header_size; /* 7, or 11 for the recyclable types */
+} tcrc_wal_record;
+
+/* Lists the physical records of a log image in file order: per 32 KiB block the
+ * (offset, length, type, verdict) sequence that ReadPhysicalRecord (db/log_reader.cc:314-406) walks,
+ * cut where the block's walk ends.  d_blocks is the result of tcrc_dev_wal_verify for the same image
+ * and log number.  Up to `capacity` records are written to d_records; *h_count receives the total
+ * (call with capacity 0 to size the array).  Returns with the list complete. */
+int tcrc_dev_wal_list(tcrc_ctx* ctx, const void* d_img, uint64_t size, uint64_t log_number,
+                      const tcrc_wal_block* d_blocks, tcrc_wal_record* d_records, uint64_t capacity,
+                      uint64_t* h_count, void* stream);
+
 /* Sets d_counts to {0, ~0, 0}. */
 int tcrc_dev_counts_reset(tcrc_ctx* ctx, uint64_t* d_counts, void* stream);
 
@@ -157,6 +178,10 @@ int tcrc_host_batch_verify(tcrc_ctx* ctx, const void* h_base, uint64_t base_byte
 /* Host form of tcrc_dev_wal_verify: h_blocks gets ceil(size/32768) entries. */
 int tcrc_host_wal_verify(tcrc_ctx* ctx, const void* h_img, uint64_t size, uint64_t log_number, tcrc_wal_block* h_blocks,
                          uint64_t* h_counts, uint64_t* h_records);
+
+/* Host form of verify + list: h_blocks (may be NULL) as in tcrc_host_wal_verify, then the record list. */
+int tcrc_host_wal_list(tcrc_ctx* ctx, const void* h_img, uint64_t size, uint64_t log_number, tcrc_wal_block* h_blocks,
+                       tcrc_wal_record* h_records, uint64_t capacity, uint64_t* h_count);
 
 /* The reference's scalar interface on host bytes: *out = crc32c::Extend(init, data, n)
  * (util/crc32c.cc:1226-1228) and crc32c::Value(data, n) (util/crc32c.h:29), computed on the GPU

@@ -63,6 +63,8 @@ SIGNATURES.update({
     "tcrc_host_blocks_stamp": (_i, [_vp, _vp, _u64, _u32, _u64, _u32, _i, _u32, _vp]),
     "tcrc_host_batch_verify": (_i, [_vp, _vp, _u64, _vp, _u64, _vp, _u32, _vp, _vp, _vp, _vp]),
     "tcrc_host_wal_verify": (_i, [_vp, _vp, _u64, _u64, _vp, _vp, C.POINTER(_u64)]),
+    "tcrc_dev_wal_list": (_i, [_vp, _vp, _u64, _u64, _vp, _vp, _u64, C.POINTER(_u64), _vp]),
+    "tcrc_host_wal_list": (_i, [_vp, _vp, _u64, _u64, _vp, _vp, _u64, C.POINTER(_u64)]),
     "tcrc_extend": (_i, [_vp, _u32, _vp, _sz, C.POINTER(_u32)]),
     "tcrc_value": (_i, [_vp, _vp, _sz, C.POINTER(_u32)]),
     "tcrc_shim_memfile_new": (_vp, []),
@@ -180,6 +182,13 @@ class Engine:
         n = C.c_uint64(0)
         check(lib.tcrc_dev_wal_verify(self.ctx, _dp(img), size, log_number, _dp(blocks), _dp(counts), C.byref(n),
                                       self._stream(stream)))
+        return n.value
+
+    def wal_list(self, img, size, log_number, blocks, records, capacity, stream=None):
+        """records: uint8 device tensor of 16 * capacity bytes (tcrc_wal_record); returns the total count."""
+        n = C.c_uint64(0)
+        check(lib.tcrc_dev_wal_list(self.ctx, _dp(img), size, log_number, _dp(blocks), _dp(records), capacity,
+                                    C.byref(n), self._stream(stream)))
         return n.value
 
     def extend_long(self, base, offsets, lens, inits, out, segment_len=0, stream=None):

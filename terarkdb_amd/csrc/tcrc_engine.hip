@@ -567,7 +567,8 @@ int tcrc_shutdown(tcrc_ctx* ctx) {
     if (ctx->d_tab_main[gi]) (void)hipFree(ctx->d_tab_main[gi]);
     if (ctx->d_tab_aux[gi]) (void)hipFree(ctx->d_tab_aux[gi]);
   }
-  for (tcrc_scratch* s : {&ctx->wal_items, &ctx->wal_item_block, &ctx->wal_misc,
+  for (tcrc_scratch* s : {&ctx->wal_items, &ctx->wal_item_block, &ctx->wal_misc, &ctx->wal_list_counts,
+                          &ctx->wal_list_first, &ctx->wal_list_temp, &ctx->host_records,
                           &ctx->host_data, &ctx->host_desc, &ctx->host_out, &ctx->host_aux, &ctx->host_blocks,
                           &ctx->long_in, &ctx->long_desc, &ctx->long_owner, &ctx->long_after, &ctx->long_pow,
                           &ctx->long_acc})

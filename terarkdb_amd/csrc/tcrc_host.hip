@@ -194,6 +194,39 @@ int tcrc_host_wal_verify(tcrc_ctx* ctx, const void* h_img, uint64_t size, uint64
   return TCRC_OK;
 }
 
+int tcrc_host_wal_list(tcrc_ctx* ctx, const void* h_img, uint64_t size, uint64_t log_number, tcrc_wal_block* h_blocks,
+                       tcrc_wal_record* h_records, uint64_t capacity, uint64_t* h_count) {
+  if (!ctx) return fail(TCRC_ERR_INVALID, "null context");
+  if (h_count) *h_count = 0;
+  if (size == 0) return TCRC_OK;
+  if (!h_img || (capacity && !h_records)) return fail(TCRC_ERR_INVALID, "null argument");
+  std::lock_guard<std::mutex> lock(ctx->host_mu);
+  if (int rc = host_begin(ctx)) return rc;
+  const uint64_t nblocks = (size + 32767) / 32768;
+  if (int rc = upload(ctx, &ctx->host_data, h_img, size)) return rc;
+  if (int rc = scratch_reserve(ctx, &ctx->host_blocks, nblocks * sizeof(tcrc_wal_block))) return rc;
+  if (int rc = scratch_reserve(ctx, &ctx->host_aux, 64)) return rc;
+  if (int rc = scratch_reserve(ctx, &ctx->host_records, (capacity ? capacity : 1) * sizeof(tcrc_wal_record))) return rc;
+  if (int rc = tcrc_dev_counts_reset(ctx, (uint64_t*)ctx->host_aux.p, ctx->host_stream)) return rc;
+  if (int rc = tcrc_dev_wal_verify(ctx, ctx->host_data.p, size, log_number, (tcrc_wal_block*)ctx->host_blocks.p,
+                                   (uint64_t*)ctx->host_aux.p, nullptr, ctx->host_stream))
+    return rc;
+  uint64_t total = 0;
+  if (int rc = tcrc_dev_wal_list(ctx, ctx->host_data.p, size, log_number, (const tcrc_wal_block*)ctx->host_blocks.p,
+                                 (tcrc_wal_record*)ctx->host_records.p, capacity, &total, ctx->host_stream))
+    return rc;
+  if (h_blocks)
+    HIP_TRY(hipMemcpyAsync(h_blocks, ctx->host_blocks.p, nblocks * sizeof(tcrc_wal_block), hipMemcpyDeviceToHost,
+                           ctx->host_stream));
+  const uint64_t n_out = total < capacity ? total : capacity;
+  if (n_out)
+    HIP_TRY(hipMemcpyAsync(h_records, ctx->host_records.p, n_out * sizeof(tcrc_wal_record), hipMemcpyDeviceToHost,
+                           ctx->host_stream));
+  HIP_TRY(hipStreamSynchronize(ctx->host_stream));
+  if (h_count) *h_count = total;
+  return TCRC_OK;
+}
+
 int tcrc_extend(tcrc_ctx* ctx, uint32_t init, const void* h_data, size_t n, uint32_t* out) {
   if (!ctx) return fail(TCRC_ERR_INVALID, "null context");
   if (!out) return fail(TCRC_ERR_INVALID, "null argument");

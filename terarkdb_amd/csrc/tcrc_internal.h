@@ -75,11 +75,11 @@ struct tcrc_ctx {
   std::string description;
   // log-scan scratch (tcrc_wal.hip): one scan at a time per context
   std::mutex wal_mu;
-  tcrc_scratch wal_items, wal_item_block, wal_misc;
+  tcrc_scratch wal_items, wal_item_block, wal_misc, wal_list_counts, wal_list_first, wal_list_temp;
   // host-pointer entry points (tcrc_host.hip): their own stream and staging, one call at a time
   std::mutex host_mu;
   hipStream_t host_stream = nullptr;
-  tcrc_scratch host_data, host_desc, host_out, host_aux, host_blocks;
+  tcrc_scratch host_data, host_desc, host_out, host_aux, host_blocks, host_records;
   // long-buffer scratch (tcrc_long.hip): one call at a time per context.  Lock order: host_mu, then
   // wal_mu or long_mu.
   std::mutex long_mu;

@@ -16,6 +16,7 @@
 //      reference drops the rest of a block at its first bad checksum
 //      (db/log_reader.cc:391-397), so that index is all the policy code needs.
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 #include <stdint.h>
 
 #include <string>
@@ -179,7 +180,94 @@ __global__ void k_wal_finish(const unsigned long long* misc, unsigned long long 
   atomicAdd(&counts[TCRC_CNT_CHECKED], misc[2 + TCRC_CNT_CHECKED]);
 }
 
+// ---- record list -----------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void k_wal_block_counts(const tcrc_wal_block* blocks, uint64_t nblocks,
+                                                          unsigned long long* counts) {
+  const uint64_t b = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  if (b <= nblocks) counts[b] = b < nblocks ? blocks[b].n_records : 0ull;  // one extra slot: the scan's total
+}
+
+struct ListParams {
+  const uint8_t* img;
+  uint64_t size;
+  uint64_t log_number;
+  uint64_t nblocks;
+  const tcrc_wal_block* blocks;
+  const unsigned long long* first;  // records before block b
+  tcrc_wal_record* out;
+  uint64_t capacity;
+};
+
+__global__ __launch_bounds__(256) void k_wal_list(ListParams p) {
+  const uint64_t blk = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  if (blk >= p.nblocks) return;
+  const uint64_t base = blk * kLogBlock;
+  const uint64_t end = base + kLogBlock < p.size ? base + kLogBlock : p.size;
+  const bool last = end == p.size;
+  const uint32_t n = p.blocks[blk].n_records, first_bad = p.blocks[blk].first_bad;
+  uint64_t slot = p.first[blk], q = base;
+  uint32_t hs = 0, len = 0, code = 0;
+  for (uint32_t k = 0; k < n; ++k, ++slot) {
+    if (!wal_step(p.img, q, end, last, p.log_number, &hs, &len, &code)) break;  // cannot happen for a matching d_blocks
+    if (slot < p.capacity) {
+      tcrc_wal_record r;
+      r.offset = q;
+      r.length = len;
+      r.type = p.img[q + 6];
+      r.status = k < first_bad ? TCRC_WAL_REC_OK : (k == first_bad ? TCRC_WAL_REC_BAD : TCRC_WAL_REC_SKIPPED);
+      r.header_size = (uint16_t)hs;
+      p.out[slot] = r;
+    }
+    q += hs + len;
+  }
+}
+
 }  // namespace
+
+extern "C" int tcrc_dev_wal_list(tcrc_ctx* ctx, const void* d_img, uint64_t size, uint64_t log_number,
+                                 const tcrc_wal_block* d_blocks, tcrc_wal_record* d_records, uint64_t capacity,
+                                 uint64_t* h_count, void* stream) {
+  if (!ctx) return fail(TCRC_ERR_INVALID, "null context");
+  if (h_count) *h_count = 0;
+  if (size == 0) return TCRC_OK;
+  if (!d_img || !d_blocks || (capacity && !d_records)) return fail(TCRC_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  std::lock_guard<std::mutex> lock(ctx->wal_mu);
+  hipStream_t s = (hipStream_t)stream;
+  const uint64_t nblocks = (size + kLogBlock - 1) / kLogBlock;
+  if (nblocks >= (1ull << 31)) return fail(TCRC_ERR_TOO_LARGE, "log image above 64 TiB");
+  const size_t words = (size_t)nblocks + 1;
+  if (int rc = scratch_reserve(ctx, &ctx->wal_list_counts, words * 8)) return rc;
+  if (int rc = scratch_reserve(ctx, &ctx->wal_list_first, words * 8)) return rc;
+  unsigned long long* counts = (unsigned long long*)ctx->wal_list_counts.p;
+  unsigned long long* first = (unsigned long long*)ctx->wal_list_first.p;
+  hipLaunchKernelGGL(k_wal_block_counts, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, d_blocks, nblocks,
+                     counts);
+  HIP_TRY(hipGetLastError());
+  size_t temp_bytes = 0;
+  HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, temp_bytes, counts, first, (int)words, s));
+  if (int rc = scratch_reserve(ctx, &ctx->wal_list_temp, temp_bytes + 256)) return rc;
+  HIP_TRY(hipcub::DeviceScan::ExclusiveSum(ctx->wal_list_temp.p, temp_bytes, counts, first, (int)words, s));
+  ListParams p{};
+  p.img = (const uint8_t*)d_img;
+  p.size = size;
+  p.log_number = log_number;
+  p.nblocks = nblocks;
+  p.blocks = d_blocks;
+  p.first = first;
+  p.out = d_records;
+  p.capacity = capacity;
+  if (capacity) {
+    hipLaunchKernelGGL(k_wal_list, dim3((unsigned)((nblocks + 255) / 256)), dim3(256), 0, s, p);
+    HIP_TRY(hipGetLastError());
+  }
+  unsigned long long total = 0;
+  HIP_TRY(hipMemcpyAsync(&total, first + nblocks, 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (h_count) *h_count = total;
+  return TCRC_OK;
+}
 
 extern "C" int tcrc_dev_wal_verify(tcrc_ctx* ctx, const void* d_img, uint64_t size, uint64_t log_number,
                                    tcrc_wal_block* d_blocks, uint64_t* d_counts, uint64_t* h_records,

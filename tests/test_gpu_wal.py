@@ -100,3 +100,60 @@ def test_many_tiny_records(eng):
     want = O.wal_scan_blocks(img, 9)
     got, counts, nrec = device_scan(eng, img, 9)
     assert (got == want).all() and nrec == int(want[:, 0].sum()) and nrec >= 30000
+
+
+REC = np.dtype([("offset", "<u8"), ("length", "<u4"), ("type", "u1"), ("status", "u1"), ("header_size", "<u2")])
+
+
+@pytest.mark.parametrize("recycle", [False, True])
+def test_record_list_matches_oracle(recycle):
+    """The (offset, length, type, verdict) list in file order, device and host forms."""
+    import ctypes as C
+    import gpu_util as G
+    import terarkdb_amd.capi as capi
+    eng = G.engine()
+    img = bytearray(O.build_wal_image(recycle, n_random=300, seed=11))
+    rng = np.random.default_rng(21)
+    for pos in rng.integers(0, len(img), 40):
+        img[int(pos)] ^= 1 << int(rng.integers(0, 8))
+    img = bytes(img)
+    want_blocks = O.wal_scan_blocks(img, 123)
+    accepted, n_acc = O.list_physical(img, 123)
+    dev = G.to_dev(np.frombuffer(img, dtype=np.uint8).copy())
+    nb = (len(img) + 32767) // 32768
+    blocks = torch.zeros((nb, 4), dtype=torch.int32, device="cuda")
+    counts = torch.zeros(3, dtype=torch.int64, device="cuda")
+    eng.counts_reset(counts)
+    total = eng.wal_verify(dev, len(img), 123, blocks, counts)
+    assert eng.wal_list(dev, len(img), 123, blocks, None, 0) == total  # sizing call
+    recs = torch.zeros(total * 16, dtype=torch.uint8, device="cuda")
+    assert eng.wal_list(dev, len(img), 123, blocks, recs, total) == total
+    torch.cuda.synchronize()
+    r = recs.cpu().numpy().view(REC)
+    assert total == int(want_blocks[:, 0].sum())
+    assert (np.diff(r["offset"].astype(np.int64)) > 0).all()  # file order
+    ok = r[r["status"] == 1]
+    assert len(ok) == n_acc
+    assert (ok["offset"] == accepted[:, 0]).all() and (ok["type"] == accepted[:, 1]).all()
+    assert (ok["length"] == accepted[:, 2]).all()
+    assert set(np.unique(ok["header_size"]).tolist()) <= {7, 11}
+    # per block: first_bad marks the one BAD record, everything after it in the block is SKIPPED
+    blk_of = (r["offset"] // 32768).astype(np.int64)
+    for b in np.nonzero(want_blocks[:, 1] != 0xffffffff)[0][:50]:
+        st = r["status"][blk_of == b]
+        fb = int(want_blocks[b, 1])
+        assert (st[:fb] == 1).all() and st[fb] == 0 and (st[fb + 1:] == 2).all()
+    # a smaller capacity returns the leading records and the full count
+    few = torch.zeros(10 * 16, dtype=torch.uint8, device="cuda")
+    assert eng.wal_list(dev, len(img), 123, blocks, few, 10) == total
+    torch.cuda.synchronize()
+    assert (few.cpu().numpy().view(REC) == r[:10]).all()
+    # host form
+    arr = np.frombuffer(img, dtype=np.uint8)
+    hrec = np.zeros(total, dtype=REC)
+    hblocks = np.zeros((nb, 4), dtype=np.uint32)
+    cnt = C.c_uint64(0)
+    capi.check(capi.lib.tcrc_host_wal_list(eng.ctx, arr.ctypes.data, len(img), 123, hblocks.ctypes.data,
+                                           hrec.ctypes.data, total, C.byref(cnt)))
+    assert cnt.value == total and (hrec == r).all() and (hblocks == want_blocks).all()
+    eng.close()
