@@ -88,7 +88,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--settle-seconds", type=float, default=1.5,
+    ap.add_argument("--settle-seconds", type=float, default=2.5,
                     help="untimed run of the same launches before the warm-up steps (clock ramp)")
     args = ap.parse_args()
 
@@ -147,10 +147,20 @@ def main():
     # The GPU raises its clocks only after about a second of sustained work; an untimed run of the
     # same launches first lets the timed steps see the steady state a long verification scan runs in.
     t_settle = time.perf_counter()
-    while time.perf_counter() - t_settle < args.settle_seconds:
-        for _ in range(50):
+    chunk_ms = []
+    while True:
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record()
+        for _ in range(100):
             step()
+        c1.record()
         torch.cuda.synchronize()
+        chunk_ms.append(c0.elapsed_time(c1))
+        waited = time.perf_counter() - t_settle
+        # stop once the clocks have been up for the minimum time and the last chunks no longer speed up
+        steady = len(chunk_ms) >= 4 and min(chunk_ms[-3:]) > 0.995 * min(chunk_ms[:-3])
+        if (waited >= args.settle_seconds and steady) or waited >= 4 * args.settle_seconds:
+            break
     for _ in range(args.warmup):
         step()
     # touch every other op of the timed region once, so no first-use set-up cost lands inside it

@@ -268,33 +268,23 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p) {
         fold_plain(d);
       }
     }
-    if (r == 0u) {
-      const uint32_t head = Rmax & 3u;
-      if (head) {
-        const uint4 a = load_checked(0);
-        uint4 b = make_uint4(0u, 0u, 0u, 0u), c = b;
-        if (head > 1u) b = load_checked(1);
-        if (head > 2u) c = load_checked(2);
-        fold_checked(a, 0);
-        if (head > 1u) fold_checked(b, 1);
-        if (head > 2u) fold_checked(c, 2);
-        r = head;
+    if (r == 0u && Rmax) {
+      // General shape.  For one buffer only its first row (leading bytes outside the message, and the
+      // initial register in message bytes 0..3) and its last row (trailing bytes outside) need the
+      // trimming of fold_checked; buffers end together, so the last row is row Rmax-1 for all of them,
+      // and a buffer's first row is row Rmax-R.  Rows [head_end, tail_begin) are whole for every buffer
+      // of the wave and go through plain bursts of four.
+      // (a buffer that starts in the last three bytes of a row has part of message bytes 0..3, which
+      // carry the initial register, in its second row too)
+      uint32_t fmax = live ? Rmax - R + (a0 > (uint32_t)(D - 4) ? 1u : 0u) : 0u;
+#pragma unroll
+      for (int o = 32; o >= G; o >>= 1) {
+        const uint32_t other = __shfl_xor(fmax, o);
+        fmax = other > fmax ? other : fmax;
       }
-    }
-    for (; r < Rmax; r += 4u) {
-      const int mg = m0 + (int)(r * D);
-      // whole wave: all four columns of the group lie inside the message, past its first four bytes
-      if (__all(live && mg >= 4 && mg + 3 * D + 16 <= (int)elen)) {
-        const uint8_t* q = ptr + mg;
-        const uint4 a = load16<NT>(q);
-        const uint4 b = load16<NT>(q + D);
-        const uint4 c = load16<NT>(q + 2 * D);
-        const uint4 d = load16<NT>(q + 3 * D);
-        fold_plain(a);
-        fold_plain(b);
-        fold_plain(c);
-        fold_plain(d);
-      } else {
+      const uint32_t head_end = fmax + 1u < Rmax ? fmax + 1u : Rmax;
+      const uint32_t tail_begin = Rmax - 1u > head_end ? Rmax - 1u : head_end;
+      for (; r + 4u <= head_end; r += 4u) {  // many only when buffers of very different lengths share the wave
         const uint4 a = load_checked(r);
         const uint4 b = load_checked(r + 1u);
         const uint4 c = load_checked(r + 2u);
@@ -304,6 +294,36 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p) {
         fold_checked(c, r + 2u);
         fold_checked(d, r + 3u);
       }
+      for (; r < head_end; ++r) fold_checked(load_checked(r), r);
+      // a buffer shorter than 16 bytes (or past the end of the batch) has no rows: its lanes fold zeros
+      const uint8_t* q = ptr + m0 + (long)r * D;
+      for (; r + 4u <= tail_begin; r += 4u, q += 4 * D) {
+        uint4 a = make_uint4(0u, 0u, 0u, 0u), b = a, c = a, d = a;
+        if (live) {
+          a = load16<NT>(q);
+          b = load16<NT>(q + D);
+          c = load16<NT>(q + 2 * D);
+          d = load16<NT>(q + 3 * D);
+        }
+        fold_plain(a);
+        fold_plain(b);
+        fold_plain(c);
+        fold_plain(d);
+      }
+      if (r < tail_begin) {
+        const uint32_t cnt = tail_begin - r;
+        uint4 a = make_uint4(0u, 0u, 0u, 0u), b = a, c = a;
+        if (live) {
+          a = load16<NT>(q);
+          if (cnt > 1u) b = load16<NT>(q + D);
+          if (cnt > 2u) c = load16<NT>(q + 2 * D);
+        }
+        fold_plain(a);
+        if (cnt > 1u) fold_plain(b);
+        if (cnt > 2u) fold_plain(c);
+        r = tail_begin;
+      }
+      for (; r < Rmax; ++r) fold_checked(load_checked(r), r);
     }
 
     // Column states -> one value per lane (bytes j*16 .. j*16+15 of the last row).
