@@ -90,7 +90,10 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p) {
   constexpr int D = 16 * G;
   constexpr int LOG2G = Geo<G>::kLog2;
   constexpr int GPW = 64 / G;  // groups (buffers) per wave
-  constexpr int kAuxDwords = (1 + LOG2G) * 1024 + D;  // reduction sets, then x^(-8t) for t < D
+  // lanes of a group that share the un-shift multiplication (a whole wave per buffer keeps it on one lane:
+  // its table would not fit next to the others, and its buffers are long enough not to care)
+  constexpr int UL = G <= 16 ? 4 : 1;
+  constexpr int kAuxDwords = (1 + LOG2G) * 1024 + D * UL;  // reduction sets, then x^(-8t) * x^(32 l / UL) for t < D, l < UL
   __shared__ uint32_t lds[kMainDwords + kAuxDwords];
 
   const int tid = threadIdx.x;
@@ -273,7 +276,7 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p) {
       // initial register in message bytes 0..3) and its last row (trailing bytes outside) need the
       // trimming of fold_checked; buffers end together, so the last row is row Rmax-1 for all of them,
       // and a buffer's first row is row Rmax-R.  Rows [head_end, tail_begin) are whole for every buffer
-      // of the wave and go through plain bursts of four.
+      // of the wave and are folded without trimming.
       // (a buffer that starts in the last three bytes of a row has part of message bytes 0..3, which
       // carry the initial register, in its second row too)
       uint32_t fmax = live ? Rmax - R + (a0 > (uint32_t)(D - 4) ? 1u : 0u) : 0u;
@@ -284,46 +287,33 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p) {
       }
       const uint32_t head_end = fmax + 1u < Rmax ? fmax + 1u : Rmax;
       const uint32_t tail_begin = Rmax - 1u > head_end ? Rmax - 1u : head_end;
-      for (; r + 4u <= head_end; r += 4u) {  // many only when buffers of very different lengths share the wave
+      // Every burst issues its (up to) four row loads together - a load is skipped by lanes whose column
+      // lies outside the message - and then folds them in order, trimmed or plain by the row's class.
+      for (; r < Rmax; r += 4u) {
+        const uint32_t cnt = Rmax - r;  // rows in this burst if fewer than four
+        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
         const uint4 a = load_checked(r);
-        const uint4 b = load_checked(r + 1u);
-        const uint4 c = load_checked(r + 2u);
-        const uint4 d = load_checked(r + 3u);
-        fold_checked(a, r);
-        fold_checked(b, r + 1u);
-        fold_checked(c, r + 2u);
-        fold_checked(d, r + 3u);
-      }
-      for (; r < head_end; ++r) fold_checked(load_checked(r), r);
-      // a buffer shorter than 16 bytes (or past the end of the batch) has no rows: its lanes fold zeros
-      const uint8_t* q = ptr + m0 + (long)r * D;
-      for (; r + 4u <= tail_begin; r += 4u, q += 4 * D) {
-        uint4 a = make_uint4(0u, 0u, 0u, 0u), b = a, c = a, d = a;
-        if (live) {
-          a = load16<NT>(q);
-          b = load16<NT>(q + D);
-          c = load16<NT>(q + 2 * D);
-          d = load16<NT>(q + 3 * D);
+        const uint4 b = cnt > 1u ? load_checked(r + 1u) : z;
+        const uint4 c = cnt > 2u ? load_checked(r + 2u) : z;
+        const uint4 d = cnt > 3u ? load_checked(r + 3u) : z;
+        if (r >= head_end && r + 4u <= tail_begin) {
+          fold_plain(a);
+          fold_plain(b);
+          fold_plain(c);
+          fold_plain(d);
+        } else {
+          if (r >= head_end && r < tail_begin) fold_plain(a); else fold_checked(a, r);
+          if (cnt > 1u) {
+            if (r + 1u >= head_end && r + 1u < tail_begin) fold_plain(b); else fold_checked(b, r + 1u);
+          }
+          if (cnt > 2u) {
+            if (r + 2u >= head_end && r + 2u < tail_begin) fold_plain(c); else fold_checked(c, r + 2u);
+          }
+          if (cnt > 3u) {
+            if (r + 3u >= head_end && r + 3u < tail_begin) fold_plain(d); else fold_checked(d, r + 3u);
+          }
         }
-        fold_plain(a);
-        fold_plain(b);
-        fold_plain(c);
-        fold_plain(d);
       }
-      if (r < tail_begin) {
-        const uint32_t cnt = tail_begin - r;
-        uint4 a = make_uint4(0u, 0u, 0u, 0u), b = a, c = a;
-        if (live) {
-          a = load16<NT>(q);
-          if (cnt > 1u) b = load16<NT>(q + D);
-          if (cnt > 2u) c = load16<NT>(q + 2 * D);
-        }
-        fold_plain(a);
-        if (cnt > 1u) fold_plain(b);
-        if (cnt > 2u) fold_plain(c);
-        r = tail_begin;
-      }
-      for (; r < Rmax; ++r) fold_checked(load_checked(r), r);
     }
 
     // Column states -> one value per lane (bytes j*16 .. j*16+15 of the last row).
@@ -338,13 +328,33 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p) {
       u ^= __shfl_up(t, d, G);
     }
 
+    // The last dword still owes its own four bytes; then the trailing zeros are taken back out:
+    // r * x^(-8 tpad).  With UL lanes the 32 shift-and-xor steps are split: lane l takes the bits
+    // [32 l / UL, 32 (l+1) / UL) of r (counted from x^0) against x^(-8 tpad) * x^(32 l / UL) from the table.
+    uint32_t rfin = fold_aux(aux, u);  // meaningful on the group's last lane
+    if (UL == 1) {
+      if (live && tpad && j == G - 1) rfin = gf2_mulmod_dev(rfin, aux[(1 + LOG2G) * 1024 + tpad]);
+    } else if (__any(live && tpad != 0u)) {
+      const uint32_t rr = __shfl(rfin, lane | (G - 1));
+      const int l = j & (UL - 1);
+      uint32_t b = aux[(1 + LOG2G) * 1024 + tpad * UL + l];
+      uint32_t part = 0;
+#pragma unroll
+      for (int k = 0; k < 32 / UL; ++k) {
+        part ^= ((rr >> (31 - (32 / UL) * l - k)) & 1u) ? b : 0u;
+        b = (b >> 1) ^ ((b & 1u) ? 0x82f63b78u : 0u);
+      }
+#pragma unroll
+      for (int o = 1; o < UL; o <<= 1) part ^= __shfl_xor(part, o);
+      if (tpad) rfin = part;
+    }
+
     uint32_t seg_owner = 0, seg_value = 0;
     bool seg_have = false;
     if (valid && j == G - 1) {
       uint32_t r;
       if (live) {
-        r = fold_aux(aux, u);  // the last dword still owes its own four bytes
-        if (tpad) r = gf2_mulmod_dev(r, aux[(1 + LOG2G) * 1024 + tpad]);  // take the trailing zeros back out
+        r = rfin;
       } else {
         r = r0;
         const uint32_t* T0 = aux + 768;  // one-byte step table
@@ -495,8 +505,8 @@ int run_batch(tcrc_ctx* ctx, BatchParams p, void* stream) {
   if (!p.base) return fail(TCRC_ERR_INVALID, "null base pointer");
   HIP_TRY(hipSetDevice(ctx->device));
   hipStream_t s = (hipStream_t)stream;
-  int g = ctx->forced_g;
-  if (p.lanes) g = p.lanes;  // the caller knows the shape of its spans (log scans)
+  int g = ctx->forced_g;  // set for experiments only
+  if (g == 0 && p.lanes) g = p.lanes;  // the caller knows the shape of its spans (log scans)
   // Log records are short (a fragment never exceeds 32 KiB, typical ones are a few KiB): four lanes
   // per record halve the end-of-buffer reduction and measured ~9 % faster on 2 KiB records.
   if (g == 0) {
@@ -555,7 +565,8 @@ int tcrc_init(int device, tcrc_ctx** out) {
     tcrc::build_shift_tables(16u * G, t);
     hipError_t e = hipMalloc(&ctx->d_tab_main[gi], sizeof(t));
     if (e == hipSuccess) e = hipMemcpy(ctx->d_tab_main[gi], t, sizeof(t), hipMemcpyHostToDevice);
-    const size_t aux_bytes = (size_t)(1 + log2g) * sizeof(t) + (size_t)16 * G * 4;
+    const int ul = G <= 16 ? 4 : 1;  // lanes sharing the un-shift multiplication (see the kernel)
+    const size_t aux_bytes = (size_t)(1 + log2g) * sizeof(t) + (size_t)16 * G * ul * 4;
     uint32_t* aux = (uint32_t*)malloc(aux_bytes);
     tcrc::build_shift_tables(4, t);
     memcpy(aux, t, sizeof(t));
@@ -563,7 +574,10 @@ int tcrc_init(int device, tcrc_ctx** out) {
       tcrc::build_shift_tables(16u << (st - 1), t);
       memcpy(aux + st * 1024, t, sizeof(t));
     }
-    for (int k = 0; k < 16 * G; ++k) aux[(1 + log2g) * 1024 + k] = tcrc::gf2_xinv_bytes((uint32_t)k);
+    for (int k = 0; k < 16 * G; ++k)
+      for (int l = 0; l < ul; ++l)  // lane l multiplies bits [32 l / ul, 32 (l+1) / ul) of the register (from x^0 up)
+        aux[(1 + log2g) * 1024 + k * ul + l] =
+            tcrc::gf2_mulmod(tcrc::gf2_xinv_bytes((uint32_t)k), tcrc::gf2_xpow(32u * l / ul));
     if (e == hipSuccess) e = hipMalloc(&ctx->d_tab_aux[gi], aux_bytes);
     if (e == hipSuccess) e = hipMemcpy(ctx->d_tab_aux[gi], aux, aux_bytes, hipMemcpyHostToDevice);
     free(aux);
