@@ -144,6 +144,19 @@ def main():
         eng.blocks_verify(data, N_BLOCKS, BLOCK_LEN, BLOCK_LEN, counts, expected=stored, out=out,
                           suffix_byte=TYPE_BYTE, stream=stream)
 
+    # Touch every other op of the timed region once first, so that no first-use set-up cost lands inside
+    # it - or between the warm-up and it: a few milliseconds of idle GPU are enough for the clocks to drop,
+    # and the launches after that run up to 10 % slower for the next hundred launches.
+    from terarkdb_amd.sharding import gather_verify_counts
+    step()
+    gather_verify_counts(counts, lambda r: r * N_BLOCKS)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    e1.record()
+    torch.cuda.synchronize()
+    _ = e0.elapsed_time(e1)
+    if dist:
+        dist.barrier()
     # The GPU raises its clocks only after about a second of sustained work; an untimed run of the
     # same launches first lets the timed steps see the steady state a long verification scan runs in.
     t_settle = time.perf_counter()
@@ -163,13 +176,6 @@ def main():
             break
     for _ in range(args.warmup):
         step()
-    # touch every other op of the timed region once, so no first-use set-up cost lands inside it
-    from terarkdb_amd.sharding import allreduce_totals
-    _ = counts.cpu()
-    allreduce_totals(0, 0, None, 0, device="cuda" if dist else None)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    e1.record()
     eng.counts_reset(counts)
     torch.cuda.synchronize()
     if dist:
@@ -183,17 +189,19 @@ def main():
     for _ in range(args.steps):
         step()
     ev_end.record()
-    c = counts.cpu().numpy().view(np.uint64)  # waits for the K launches
-    fb_local = int(c[capi.CNT_FIRST_BAD])
-    # the path's only exchange: every rank's {mismatches, checked, first bad block}, one all-gather (RCCL)
-    totals = allreduce_totals(int(c[capi.CNT_MISMATCH]), int(c[capi.CNT_CHECKED]),
-                              None if fb_local == 2**64 - 1 else fb_local, rank * N_BLOCKS,
-                              device="cuda" if dist else None)
+    t_enq = time.perf_counter()
+    # the path's only exchange: every rank's {mismatches, first bad block, checked}, one all-gather (RCCL)
+    # of the engine's device counter block; the copy to the host waits for the K launches
+    totals = gather_verify_counts(counts, lambda r: r * N_BLOCKS)
+    t_cnt = time.perf_counter()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if os.environ.get("BENCH_DEBUG"):
+        print(f"[rank {rank}] enqueue {1e6*(t_enq-t0):.0f} us, counters back {1e6*(t_cnt-t0):.0f} us, "
+              f"end {1e6*elapsed:.0f} us", file=sys.stderr)
     if dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

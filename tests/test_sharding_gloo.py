@@ -18,7 +18,7 @@ import os, sys
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
 import numpy as np, torch, torch.distributed as dist
 import oracle_lib as O
-from terarkdb_amd.sharding import shard_range, allreduce_totals
+from terarkdb_amd.sharding import shard_range, allreduce_totals, gather_verify_counts
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
 n, blen = 1003, 4096
@@ -32,6 +32,13 @@ mine = O.sst_trailer_batch(corpus[lo * blen: hi * blen], blen, blen, hi - lo, 0)
 wrong = np.nonzero(mine != stored[lo:hi])[0]
 t = allreduce_totals(len(wrong), hi - lo, int(wrong[0]) if len(wrong) else None, lo)
 assert (t.mismatches, t.checked, t.first_bad) == (len(bad), n, 17), t
+# the same exchange straight from an engine-style counter block {mismatches, first bad local or ~0, checked}
+block = torch.tensor([len(wrong), int(wrong[0]) if len(wrong) else -1, hi - lo], dtype=torch.int64)
+spans = [shard_range(n, r, world) for r in range(world)]
+g = gather_verify_counts(block, lambda r: spans[r][0])
+assert (g.mismatches, g.checked, g.first_bad) == (len(bad), n, 17), g
+clean = gather_verify_counts(torch.tensor([0, -1, hi - lo], dtype=torch.int64), lambda r: spans[r][0])
+assert (clean.mismatches, clean.checked, clean.first_bad) == (0, n, -1), clean
 print("rank", rank, "ok", t)
 dist.destroy_process_group()
 """
