@@ -609,6 +609,9 @@ int tcrc_shutdown(tcrc_ctx* ctx) {
     scratch_release(s);
   if (ctx->host_stream) (void)hipStreamDestroy(ctx->host_stream);
   for (auto& e : ctx->pin_free) (void)hipHostFree(e.first);
+  if (ctx->stage_ring) (void)hipHostFree(ctx->stage_ring);
+  for (hipEvent_t ev : ctx->stage_done)
+    if (ev) (void)hipEventDestroy(ev);
   delete ctx;
   return TCRC_OK;
 }

@@ -6,7 +6,10 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <atomic>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "tcrc_internal.h"
 
@@ -20,8 +23,76 @@ int host_begin(tcrc_ctx* ctx) {
   return TCRC_OK;
 }
 
+// True when p is host memory the DMA engines can read directly (allocated or registered pinned).
+bool is_pinned(const void* p) {
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+    (void)hipGetLastError();  // ordinary pageable memory is "invalid value" to the runtime
+    return false;
+  }
+  return a.type == hipMemoryTypeHost;
+}
+
+// Copies pageable host memory to the device through a ring of pinned slots: several host threads
+// fill slots while the copy engine drains them, which roughly doubles the rate of a plain
+// hipMemcpy from pageable memory (the runtime stages through one thread).
+int staged_upload(tcrc_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
+  constexpr int K = tcrc_ctx::kStageSlots;
+  constexpr size_t S = tcrc_ctx::kStageSlotBytes;
+  if (!ctx->stage_ring) {
+    HIP_TRY(hipHostMalloc((void**)&ctx->stage_ring, K * S, hipHostMallocDefault));
+    for (int i = 0; i < K; ++i) HIP_TRY(hipEventCreateWithFlags(&ctx->stage_done[i], hipEventDisableTiming));
+  }
+  const size_t n = (bytes + S - 1) / S;
+  std::vector<std::atomic<int>> filled(n), issued(n);
+  for (size_t i = 0; i < n; ++i) {
+    filled[i].store(0, std::memory_order_relaxed);
+    issued[i].store(0, std::memory_order_relaxed);
+  }
+  std::atomic<size_t> next{0};
+  std::atomic<int> failed{0};
+  const int device = ctx->device;
+  auto worker = [&]() {
+    (void)hipSetDevice(device);
+    for (;;) {
+      const size_t i = next.fetch_add(1);
+      if (i >= n || failed.load()) return;
+      if (i >= (size_t)K) {  // the slot still holds chunk i-K until its copy has been issued and has finished
+        while (!issued[i - K].load(std::memory_order_acquire))
+          if (failed.load()) return; else std::this_thread::yield();
+        if (hipEventSynchronize(ctx->stage_done[i % K]) != hipSuccess) {
+          failed.store(1);
+          return;
+        }
+      }
+      const size_t off = i * S, len = bytes - off < S ? bytes - off : S;
+      memcpy(ctx->stage_ring + (i % K) * S, (const char*)h_src + off, len);
+      filled[i].store(1, std::memory_order_release);
+    }
+  };
+  const int nthreads = (int)(n < 6 ? n : 6);
+  std::vector<std::thread> pool;
+  for (int t = 0; t < nthreads; ++t) pool.emplace_back(worker);
+  hipError_t err = hipSuccess;
+  for (size_t i = 0; i < n && err == hipSuccess; ++i) {
+    while (!filled[i].load(std::memory_order_acquire))
+      if (failed.load()) break; else std::this_thread::yield();
+    if (failed.load()) break;
+    const size_t off = i * S, len = bytes - off < S ? bytes - off : S;
+    err = hipMemcpyAsync((char*)d_dst + off, ctx->stage_ring + (i % K) * S, len, hipMemcpyHostToDevice, ctx->host_stream);
+    if (err == hipSuccess) err = hipEventRecord(ctx->stage_done[i % K], ctx->host_stream);
+    issued[i].store(1, std::memory_order_release);
+  }
+  if (err != hipSuccess) failed.store(1);
+  for (auto& t : pool) t.join();
+  if (err != hipSuccess) return fail(TCRC_ERR_HIP, std::string("staged upload: ") + hipGetErrorString(err));
+  if (failed.load()) return fail(TCRC_ERR_HIP, "staged upload: a staging thread failed");
+  return TCRC_OK;
+}
+
 int upload(tcrc_ctx* ctx, tcrc_scratch* s, const void* h, size_t bytes, size_t slack = 64) {
   if (int rc = scratch_reserve(ctx, s, bytes + slack)) return rc;
+  if (bytes >= ((size_t)16 << 20) && !is_pinned(h)) return staged_upload(ctx, s->p, h, bytes);
   if (bytes) HIP_TRY(hipMemcpyAsync(s->p, h, bytes, hipMemcpyHostToDevice, ctx->host_stream));
   return TCRC_OK;
 }

@@ -86,6 +86,11 @@ struct tcrc_ctx {
   tcrc_scratch long_in, long_desc, long_owner, long_after, long_pow, long_acc;
   uint32_t long_pow_seg = 0;      // segment length the cached power table was built for
   uint32_t long_pow_count = 0;    // entries in it
+  // Staging ring for uploads from pageable memory (tcrc_host.hip), guarded by host_mu
+  static constexpr int kStageSlots = 12;
+  static constexpr size_t kStageSlotBytes = (size_t)4 << 20;
+  char* stage_ring = nullptr;  // kStageSlots * kStageSlotBytes of pinned memory
+  hipEvent_t stage_done[kStageSlots] = {};
   // Pinned host buffers handed back through tcrc_host_free, kept for the next tcrc_host_alloc:
   // pinning memory costs about as much as copying it, and callers allocate staging per call.
   std::mutex pin_mu;
