@@ -199,6 +199,12 @@ int tcrc_value(tcrc_ctx* ctx, const void* h_data, size_t n, uint32_t* out);
 int tcrc_dev_probe_read(tcrc_ctx* ctx, const void* d_base, uint64_t nbytes, uint32_t* d_scratch, uint32_t wgs_per_cu,
                         void* stream);
 
+/* The lookup tables the kernels use for `lanes` lanes per buffer (4, 8, 16 or 64), as built on the host
+ * at tcrc_init: main_out gets the 1024 words of Z_D (D = 16 * lanes), aux_out the reduction sets and the
+ * inverse-shift multipliers; *aux_words their count.  Needs no GPU.  For tests that model the kernel's
+ * arithmetic on the CPU; the reference's counterpart is its static table0_..table3_ (util/crc32c.cc:50-313). */
+int tcrc_debug_tables(int lanes, uint32_t* main_out, uint32_t* aux_out, size_t aux_capacity, size_t* aux_words);
+
 #ifdef __cplusplus
 }
 #endif

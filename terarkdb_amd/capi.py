@@ -65,6 +65,7 @@ SIGNATURES.update({
     "tcrc_host_wal_verify": (_i, [_vp, _vp, _u64, _u64, _vp, _vp, C.POINTER(_u64)]),
     "tcrc_dev_wal_list": (_i, [_vp, _vp, _u64, _u64, _vp, _vp, _u64, C.POINTER(_u64), _vp]),
     "tcrc_host_wal_list": (_i, [_vp, _vp, _u64, _u64, _vp, _vp, _u64, C.POINTER(_u64)]),
+    "tcrc_debug_tables": (_i, [_i, _vp, _vp, _sz, C.POINTER(_sz)]),
     "tcrc_extend": (_i, [_vp, _u32, _vp, _sz, C.POINTER(_u32)]),
     "tcrc_value": (_i, [_vp, _vp, _sz, C.POINTER(_u32)]),
     "tcrc_shim_memfile_new": (_vp, []),

@@ -471,6 +471,31 @@ int launch_batch(tcrc_ctx* ctx, BatchParams p, hipStream_t s) {
 
 namespace tcrc_internal {
 
+// The lookup sets one geometry (G lanes per buffer, rows of D = 16 G bytes) keeps in LDS:
+//   main: Z_D as four 256-entry tables (replicated 32x when copied into LDS);
+//   aux:  Z_4, then Z_16, Z_32, ... Z_(8 G) for the lane reduction (1 + log2 G sets of 1024 words),
+//         then x^(-8 t) * x^(32 l / UL) for t < D and l < UL, the multipliers that take t trailing zero
+//         bytes back out, pre-shifted for each of the UL lanes that share the multiplication.
+void build_tables(int G, std::vector<uint32_t>* main_tab, std::vector<uint32_t>* aux) {
+  int log2g = 0;
+  while ((1 << log2g) < G) ++log2g;
+  const int ul = G <= 16 ? 4 : 1;
+  uint32_t t[4][256];
+  tcrc::build_shift_tables(16u * G, t);
+  main_tab->assign(&t[0][0], &t[0][0] + 1024);
+  aux->assign((size_t)(1 + log2g) * 1024 + (size_t)16 * G * ul, 0u);
+  tcrc::build_shift_tables(4, t);
+  memcpy(aux->data(), t, sizeof(t));
+  for (int st = 1; st <= log2g; ++st) {
+    tcrc::build_shift_tables(16u << (st - 1), t);
+    memcpy(aux->data() + st * 1024, t, sizeof(t));
+  }
+  for (int k = 0; k < 16 * G; ++k)
+    for (int l = 0; l < ul; ++l)  // lane l multiplies bits [32 l / ul, 32 (l+1) / ul) of the register (from x^0 up)
+      (*aux)[(size_t)(1 + log2g) * 1024 + k * ul + l] =
+          tcrc::gf2_mulmod(tcrc::gf2_xinv_bytes((uint32_t)k), tcrc::gf2_xpow(32u * l / ul));
+}
+
 thread_local std::string g_err;
 
 int fail(int code, const std::string& msg) {
@@ -561,26 +586,13 @@ int tcrc_init(int device, tcrc_ctx** out) {
     const int G = kGeoLanes[gi];
     int log2g = 0;
     while ((1 << log2g) < G) ++log2g;
-    uint32_t t[4][256];
-    tcrc::build_shift_tables(16u * G, t);
-    hipError_t e = hipMalloc(&ctx->d_tab_main[gi], sizeof(t));
-    if (e == hipSuccess) e = hipMemcpy(ctx->d_tab_main[gi], t, sizeof(t), hipMemcpyHostToDevice);
-    const int ul = G <= 16 ? 4 : 1;  // lanes sharing the un-shift multiplication (see the kernel)
-    const size_t aux_bytes = (size_t)(1 + log2g) * sizeof(t) + (size_t)16 * G * ul * 4;
-    uint32_t* aux = (uint32_t*)malloc(aux_bytes);
-    tcrc::build_shift_tables(4, t);
-    memcpy(aux, t, sizeof(t));
-    for (int st = 1; st <= log2g; ++st) {
-      tcrc::build_shift_tables(16u << (st - 1), t);
-      memcpy(aux + st * 1024, t, sizeof(t));
-    }
-    for (int k = 0; k < 16 * G; ++k)
-      for (int l = 0; l < ul; ++l)  // lane l multiplies bits [32 l / ul, 32 (l+1) / ul) of the register (from x^0 up)
-        aux[(1 + log2g) * 1024 + k * ul + l] =
-            tcrc::gf2_mulmod(tcrc::gf2_xinv_bytes((uint32_t)k), tcrc::gf2_xpow(32u * l / ul));
-    if (e == hipSuccess) e = hipMalloc(&ctx->d_tab_aux[gi], aux_bytes);
-    if (e == hipSuccess) e = hipMemcpy(ctx->d_tab_aux[gi], aux, aux_bytes, hipMemcpyHostToDevice);
-    free(aux);
+    std::vector<uint32_t> main_tab, aux;
+    build_tables(G, &main_tab, &aux);
+    hipError_t e = hipMalloc(&ctx->d_tab_main[gi], main_tab.size() * 4);
+    if (e == hipSuccess)
+      e = hipMemcpy(ctx->d_tab_main[gi], main_tab.data(), main_tab.size() * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(&ctx->d_tab_aux[gi], aux.size() * 4);
+    if (e == hipSuccess) e = hipMemcpy(ctx->d_tab_aux[gi], aux.data(), aux.size() * 4, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
       tcrc_shutdown(ctx);
       return fail(TCRC_ERR_HIP, std::string("table upload: ") + hipGetErrorString(e));
@@ -591,6 +603,19 @@ int tcrc_init(int device, tcrc_ctx** out) {
            ctx->cus);
   ctx->description = buf;
   *out = ctx;
+  return TCRC_OK;
+}
+
+int tcrc_debug_tables(int lanes, uint32_t* main_out, uint32_t* aux_out, size_t aux_capacity, size_t* aux_words) {
+  if (geo_index(lanes) < 0) return fail(TCRC_ERR_INVALID, "lanes must be 4, 8, 16 or 64");
+  std::vector<uint32_t> main_tab, aux;
+  build_tables(lanes, &main_tab, &aux);
+  if (aux_words) *aux_words = aux.size();
+  if (main_out) memcpy(main_out, main_tab.data(), 4096);
+  if (aux_out) {
+    if (aux_capacity < aux.size()) return fail(TCRC_ERR_INVALID, "aux_capacity too small");
+    memcpy(aux_out, aux.data(), aux.size() * 4);
+  }
   return TCRC_OK;
 }
 

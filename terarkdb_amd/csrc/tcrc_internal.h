@@ -47,6 +47,9 @@ constexpr int kGeoCount = 4;
 
 int fail(int code, const std::string& msg);
 
+// Host-side construction of the lookup tables of one geometry (tcrc_engine.hip).
+void build_tables(int G, std::vector<uint32_t>* main_tab, std::vector<uint32_t>* aux);
+
 // Launches the batch CRC kernel for the geometry the context prefers.
 int run_batch(tcrc_ctx* ctx, BatchParams p, void* stream);
 
