@@ -644,6 +644,18 @@ void oracle_wal_scan_blocks(const uint8_t* img, size_t n, uint64_t log_number, u
   }
 }
 
+/* n logical records of rec_len bytes each, back to back in data: the loop a group commit runs over the
+ * reference writer (db/db_impl_write.cc:834-939 calls AddRecord once per merged batch; this is the same
+ * writer fed many records, for timing the CPU side of the group-commit comparison). */
+int oracle_wal_writer_add_records_fixed(void* writer, const void* data, size_t rec_len, size_t n) {
+  const uint8_t* p = (const uint8_t*)data;
+  for (size_t i = 0; i < n; i++) {
+    int rc = oracle_wal_writer_add_record(writer, p + i * rec_len, rec_len);
+    if (rc != 0) return rc;
+  }
+  return 0;
+}
+
 /* The log of the CPU-reference configuration: n logical records, each a write batch of one
  * Put (db/write_batch.cc:10-34: fixed64 sequence, fixed32 count = 1, tag kTypeValue = 1,
  * varint32 key length + key, varint32 value length + value) with a 24-byte key (first 8

@@ -38,6 +38,7 @@ def lib():
             "oracle_sink_rewind_for_overwrite": (None, [vp]),
             "oracle_sink_append_raw": (None, [vp, C.c_char_p, sz]),
             "oracle_wal_writer_new": (vp, [vp, u64, i]),
+            "oracle_wal_writer_add_records_fixed": (i, [vp, vp, sz, sz]),
             "oracle_wal_writer_free": (None, [vp]),
             "oracle_wal_writer_use_hw": (None, [vp, i]),
             "oracle_wal_writer_type_crc": (u32, [vp, i]),

@@ -176,6 +176,28 @@ def main():
         "note": "AddRecord x k framed on the host into pinned staging, one device submission at WriteBuffer(); "
                 "the first group also grows the staging buffer",
     }
+    # group size at which one device submission beats the CPU writer on one core
+    cross = []
+    for kg in (1, 4, 16, 64, 256, 1024, 4096, min(k, 15000)):
+        best_dev = best_cpu = None
+        for _ in range(5):
+            t0 = time.perf_counter()
+            assert L.tcrc_shim_wal_writer_add_records_fixed(w, flat.ctypes.data, 2040, kg) == 0
+            assert L.tcrc_shim_wal_writer_write_buffer(w) == 0
+            dt = time.perf_counter() - t0
+            best_dev = dt if best_dev is None else min(best_dev, dt)
+        tc = O.OracleLog(recycle=False, log_number=7, hw=True)
+        for _ in range(5):
+            t0 = time.perf_counter()
+            OL.oracle_wal_writer_add_records_fixed(tc.writer, flat.ctypes.data, 2040, kg)
+            dt = time.perf_counter() - t0
+            best_cpu = dt if best_cpu is None else min(best_cpu, dt)
+        tc.close()
+        cross.append({"records": kg, "bytes": kg * 2040, "engine_us": round(best_dev * 1e6, 1),
+                      "cpu_one_core_us": round(best_cpu * 1e6, 1)})
+    res["group_commit_crossover"] = {"rows": cross, "note": "2040-byte records per group; engine = framing on the host "
+                                     "+ one device submission + append to an in-memory file; cpu = the oracle writer "
+                                     "(SSE4.2 path) appending to an in-memory file, one thread"}
     t0 = time.perf_counter()
     w2 = L.tcrc_shim_wal_writer_new(eng.ctx, L.tcrc_shim_memfile_new(), 7, 0, 0, 0)
     kk = 2000
