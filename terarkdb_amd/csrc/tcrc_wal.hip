@@ -102,10 +102,15 @@ __device__ __forceinline__ uint32_t wave_exclusive_sum(uint32_t v, uint32_t lane
 
 // One thread per 32 KiB block.  Pass 1 counts the block's short and long records; the 64 counts of a
 // wave are prefix-summed with shuffles and the wave takes its runs of descriptor slots with ONE atomic
-// add per list; pass 2 walks the (now cached) headers again and writes the descriptors.  Descriptors
+// add per list; pass 2 writes the descriptors from the header facts pass 1 kept in LDS (it walks memory
+// again only past the 32nd record of a block).  Descriptors
 // of one block are contiguous within a list, blocks land in no particular order - nothing downstream
 // depends on it.
 __global__ __launch_bounds__(256) void k_wal_walk(WalkParams p) {
+  // (header position, header size, payload length) of the first kCached records of every block, kept
+  // from the counting pass so that the emitting pass does not chase the headers through memory again
+  constexpr uint32_t kCached = 32;
+  __shared__ uint32_t cache[kCached * 256];
   const uint32_t blk = blockIdx.x * 256u + threadIdx.x;
   const bool have = blk < p.nblocks;
   const uint64_t base = (uint64_t)blk * kLogBlock;
@@ -115,6 +120,9 @@ __global__ __launch_bounds__(256) void k_wal_walk(WalkParams p) {
   uint64_t pos = base;
   if (have) {
     while (wal_step(p.img, pos, end, last, p.log_number, &hs, &len, &code)) {
+      // 15 bits of position, 1 bit of header kind, 16 bits of length
+      if (n < kCached)
+        cache[n * 256u + threadIdx.x] = (uint32_t)(pos - base) | (hs == kRecyclableHeader ? 0x8000u : 0u) | (len << 16);
       ++n;
       if (len + hs - 6 >= kLongSpan) ++n_long;
       pos += hs + len;
@@ -133,8 +141,15 @@ __global__ __launch_bounds__(256) void k_wal_walk(WalkParams p) {
   uint64_t slot_s = base_s + excl_s, slot_l = base_l + excl_l;
   uint64_t q = base;
   for (uint32_t k = 0; k < n; ++k) {
-    uint32_t c2;
-    wal_step(p.img, q, end, last, p.log_number, &hs, &len, &c2);
+    if (k < kCached) {
+      const uint32_t c = cache[k * 256u + threadIdx.x];
+      q = base + (c & 0x7fffu);
+      hs = (c & 0x8000u) ? kRecyclableHeader : kHeader;
+      len = c >> 16;
+    } else {
+      uint32_t c2;
+      wal_step(p.img, q, end, last, p.log_number, &hs, &len, &c2);
+    }
     tcrc_desc d;
     d.offset = q + 6;  // the CRC covers the type byte, the log number if any, and the payload
     d.len = len + hs - 6;
