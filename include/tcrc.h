@@ -157,6 +157,21 @@ int tcrc_dev_wal_list(tcrc_ctx* ctx, const void* d_img, uint64_t size, uint64_t 
                       const tcrc_wal_block* d_blocks, tcrc_wal_record* d_records, uint64_t capacity,
                       uint64_t* h_count, void* stream);
 
+/* Frames logical records that are already in device memory into a log image in device memory, the
+ * way n calls of log::Writer::AddRecord append them (db/log_writer.cc:45-151): fragments that never
+ * cross a 32 KiB block, 7-byte headers (11 with the log number when recycle != 0), zero-filled block
+ * tails shorter than a header, and Mask(crc32c(type | [log number] | payload)) in every header.
+ * Record i is the h_recs[i].len bytes at d_src + h_recs[i].offset (h_recs[i].init is ignored).
+ * block_offset is the position inside the current 32 KiB block at which the image continues an
+ * existing log (0 for a new file); *block_offset_out (may be NULL) is that position after the call.
+ * *h_written receives the image size; tcrc_wal_framed_size gives it beforehand.  d_dst must not
+ * overlap d_src.  Returns with the image complete. */
+int tcrc_dev_wal_frame(tcrc_ctx* ctx, const void* d_src, const tcrc_desc* h_recs, uint64_t n, uint64_t log_number,
+                       int recycle, uint32_t block_offset, void* d_dst, uint64_t dst_capacity, uint64_t* h_written,
+                       uint32_t* block_offset_out, uint64_t* h_physical_records, void* stream);
+/* Bytes tcrc_dev_wal_frame will write for these records (host arithmetic on the lengths only). */
+uint64_t tcrc_wal_framed_size(const tcrc_desc* h_recs, uint64_t n, int recycle, uint32_t block_offset);
+
 /* Sets d_counts to {0, ~0, 0}. */
 int tcrc_dev_counts_reset(tcrc_ctx* ctx, uint64_t* d_counts, void* stream);
 

@@ -63,6 +63,9 @@ SIGNATURES.update({
     "tcrc_host_blocks_stamp": (_i, [_vp, _vp, _u64, _u32, _u64, _u32, _i, _u32, _vp]),
     "tcrc_host_batch_verify": (_i, [_vp, _vp, _u64, _vp, _u64, _vp, _u32, _vp, _vp, _vp, _vp]),
     "tcrc_host_wal_verify": (_i, [_vp, _vp, _u64, _u64, _vp, _vp, C.POINTER(_u64)]),
+    "tcrc_dev_wal_frame": (_i, [_vp, _vp, _vp, _u64, _u64, _i, _u32, _vp, _u64, C.POINTER(_u64), C.POINTER(_u32),
+                                C.POINTER(_u64), _vp]),
+    "tcrc_wal_framed_size": (_u64, [_vp, _u64, _i, _u32]),
     "tcrc_dev_wal_list": (_i, [_vp, _vp, _u64, _u64, _vp, _vp, _u64, C.POINTER(_u64), _vp]),
     "tcrc_host_wal_list": (_i, [_vp, _vp, _u64, _u64, _vp, _vp, _u64, C.POINTER(_u64)]),
     "tcrc_debug_tables": (_i, [_i, _vp, _vp, _sz, C.POINTER(_sz)]),
@@ -184,6 +187,18 @@ class Engine:
         check(lib.tcrc_dev_wal_verify(self.ctx, _dp(img), size, log_number, _dp(blocks), _dp(counts), C.byref(n),
                                       self._stream(stream)))
         return n.value
+
+    def wal_frame(self, src, offsets, lens, log_number, recycle, dst, block_offset=0, stream=None):
+        """Frames the records src[offsets[i] : offsets[i] + lens[i]] into dst (both device uint8 tensors);
+        returns (bytes written, block offset afterwards, physical records)."""
+        n = len(offsets)
+        arr = (Desc * max(n, 1))()
+        for i in range(n):
+            arr[i].offset, arr[i].len, arr[i].init = int(offsets[i]), int(lens[i]), 0
+        written, bo, phys = C.c_uint64(0), C.c_uint32(0), C.c_uint64(0)
+        check(lib.tcrc_dev_wal_frame(self.ctx, _dp(src), arr, n, log_number, int(recycle), block_offset, _dp(dst),
+                                     dst.numel(), C.byref(written), C.byref(bo), C.byref(phys), self._stream(stream)))
+        return written.value, bo.value, phys.value
 
     def wal_list(self, img, size, log_number, blocks, records, capacity, stream=None):
         """records: uint8 device tensor of 16 * capacity bytes (tcrc_wal_record); returns the total count."""

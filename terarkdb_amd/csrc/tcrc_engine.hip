@@ -374,8 +374,14 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p) {
         seg_owner = p.seg_owner[buf];
         seg_value = q == 0 ? ~prod : prod;
         seg_have = true;
-      } else if (p.out) {
-        p.out[buf] = (p.flags & TCRC_F_MASK) ? masked : crc;
+      } else {
+        const uint32_t result = (p.flags & TCRC_F_MASK) ? masked : crc;
+        if (p.out) p.out[buf] = result;
+        if ((p.flags & kFlagStampBefore) && len != 0u) {
+          // into the record header of a log image being framed (the image is writable there)
+          uint8_t* h = const_cast<uint8_t*>(p.base) + off - 6;
+          __builtin_memcpy(h, &result, 4);
+        }
       }
       if (p.verify) {
         const bool good = stored == masked;
@@ -627,7 +633,7 @@ int tcrc_shutdown(tcrc_ctx* ctx) {
     if (ctx->d_tab_aux[gi]) (void)hipFree(ctx->d_tab_aux[gi]);
   }
   for (tcrc_scratch* s : {&ctx->wal_items, &ctx->wal_item_block, &ctx->wal_misc, &ctx->wal_list_counts,
-                          &ctx->wal_list_first, &ctx->wal_list_temp, &ctx->host_records,
+                          &ctx->wal_list_first, &ctx->wal_list_temp, &ctx->wal_frags, &ctx->host_records,
                           &ctx->host_data, &ctx->host_desc, &ctx->host_out, &ctx->host_aux, &ctx->host_blocks,
                           &ctx->long_in, &ctx->long_desc, &ctx->long_owner, &ctx->long_after, &ctx->long_pow,
                           &ctx->long_acc})

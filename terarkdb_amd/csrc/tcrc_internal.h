@@ -15,6 +15,7 @@ namespace tcrc_internal {
 // internal flag bits (above the public TCRC_F_* ones)
 constexpr uint32_t kFlagWalItems = 0x100u;  // descriptors are log records: desc.init = index inside the 32 KiB block
 constexpr uint32_t kFlagSegments = 0x200u;  // descriptors are segments of longer buffers: results are shifted and XORed
+constexpr uint32_t kFlagStampBefore = 0x400u;  // the result is also stored as LE32 six bytes before the buffer (log header)
 
 struct BatchParams {
   const uint8_t* base;
@@ -78,7 +79,7 @@ struct tcrc_ctx {
   std::string description;
   // log-scan scratch (tcrc_wal.hip): one scan at a time per context
   std::mutex wal_mu;
-  tcrc_scratch wal_items, wal_item_block, wal_misc, wal_list_counts, wal_list_first, wal_list_temp;
+  tcrc_scratch wal_items, wal_item_block, wal_misc, wal_list_counts, wal_list_first, wal_list_temp, wal_frags;
   // host-pointer entry points (tcrc_host.hip): their own stream and staging, one call at a time
   std::mutex host_mu;
   hipStream_t host_stream = nullptr;

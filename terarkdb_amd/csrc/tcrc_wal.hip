@@ -238,7 +238,161 @@ __global__ __launch_bounds__(256) void k_wal_list(ListParams p) {
   }
 }
 
+// ---- framing ---------------------------------------------------------------------------------
+
+// One piece of the image: a physical record (header + payload copied from src) or, with type 0xff,
+// a run of zero bytes (the tail of a block too short for a header).
+struct Frag {
+  uint64_t src;  // payload offset in the source
+  uint64_t dst;  // offset of the header (or of the zero run) in the image
+  uint32_t len;  // payload bytes (or zero bytes)
+  uint32_t type;
+};
+
+struct FrameParams {
+  const uint8_t* src;
+  uint8_t* dst;
+  const Frag* frags;
+  uint32_t nfrags;
+  uint32_t header_size;
+  uint32_t log_number;
+  tcrc_desc* spans;  // out: the checksummed span of every physical record (len 0 for zero runs)
+};
+
+// One wave per piece: header bytes, then the payload in 16-byte steps.
+__global__ __launch_bounds__(256) void k_wal_frame(FrameParams p) {
+  const uint32_t f = blockIdx.x * 4u + (threadIdx.x >> 6);
+  if (f >= p.nfrags) return;
+  const uint32_t lane = threadIdx.x & 63u;
+  const Frag g = p.frags[f];
+  uint8_t* out = p.dst + g.dst;
+  if (g.type == 0xffu) {
+    for (uint32_t i = lane; i < g.len; i += 64u) out[i] = 0;
+    if (lane == 0) p.spans[f] = tcrc_desc{0, 0, 0};
+    return;
+  }
+  const uint32_t hs = p.header_size;
+  if (lane == 0) {
+    out[0] = out[1] = out[2] = out[3] = 0;  // checksum: filled in by the CRC kernel
+    out[4] = (uint8_t)(g.len & 0xffu);
+    out[5] = (uint8_t)(g.len >> 8);
+    out[6] = (uint8_t)g.type;
+    if (hs == kRecyclableHeader) {
+      out[7] = (uint8_t)p.log_number;
+      out[8] = (uint8_t)(p.log_number >> 8);
+      out[9] = (uint8_t)(p.log_number >> 16);
+      out[10] = (uint8_t)(p.log_number >> 24);
+    }
+    tcrc_desc d;
+    d.offset = g.dst + 6;
+    d.len = g.len + hs - 6;
+    d.init = 0;
+    p.spans[f] = d;
+  }
+  const uint8_t* in = p.src + g.src;
+  uint8_t* body = out + hs;
+  const uint32_t whole = g.len & ~15u;
+  for (uint32_t i = lane * 16u; i < whole; i += 1024u) {
+    uint4 v;
+    __builtin_memcpy(&v, in + i, 16);
+    __builtin_memcpy(body + i, &v, 16);
+  }
+  if (lane < (g.len & 15u)) body[whole + lane] = in[whole + lane];
+}
+
+// The fragmentation rules of db/log_writer.cc:45-100 as a list of pieces; returns the image size.
+uint64_t plan_frames(const tcrc_desc* recs, uint64_t n, bool recycle, uint32_t block_offset, std::vector<Frag>* out,
+                     uint32_t* block_offset_out, uint64_t* physical) {
+  const uint32_t hs = recycle ? kRecyclableHeader : kHeader;
+  const uint32_t base_type = recycle ? 4u : 0u;  // recyclable types are the legacy ones + 4 (db/log_format.h:19-35)
+  uint64_t pos = 0, phys = 0;
+  uint32_t bo = block_offset;
+  for (uint64_t i = 0; i < n; ++i) {
+    uint64_t src = recs[i].offset;
+    uint32_t left = recs[i].len;
+    bool first = true;
+    for (;;) {
+      const uint32_t room = kLogBlock - bo;
+      if (room < hs) {
+        if (room > 0) {
+          if (out) out->push_back(Frag{0, pos, room, 0xffu});
+          pos += room;
+        }
+        bo = 0;
+      }
+      const uint32_t avail = kLogBlock - bo - hs;
+      const uint32_t take = left < avail ? left : avail;
+      const bool last = take == left;
+      const uint32_t t = first ? (last ? 1u : 2u) : (last ? 4u : 3u);  // full, first, last, middle
+      if (out) out->push_back(Frag{src, pos, take, t + base_type});
+      pos += hs + take;
+      bo += hs + take;
+      src += take;
+      left -= take;
+      first = false;
+      ++phys;
+      if (left == 0) break;
+    }
+  }
+  if (block_offset_out) *block_offset_out = bo;
+  if (physical) *physical = phys;
+  return pos;
+}
+
 }  // namespace
+
+extern "C" uint64_t tcrc_wal_framed_size(const tcrc_desc* h_recs, uint64_t n, int recycle, uint32_t block_offset) {
+  if (!h_recs || block_offset >= kLogBlock) return 0;
+  return plan_frames(h_recs, n, recycle != 0, block_offset, nullptr, nullptr, nullptr);
+}
+
+extern "C" int tcrc_dev_wal_frame(tcrc_ctx* ctx, const void* d_src, const tcrc_desc* h_recs, uint64_t n,
+                                  uint64_t log_number, int recycle, uint32_t block_offset, void* d_dst,
+                                  uint64_t dst_capacity, uint64_t* h_written, uint32_t* block_offset_out,
+                                  uint64_t* h_physical_records, void* stream) {
+  if (!ctx) return fail(TCRC_ERR_INVALID, "null context");
+  if (h_written) *h_written = 0;
+  if (h_physical_records) *h_physical_records = 0;
+  if (block_offset_out) *block_offset_out = block_offset;
+  if (block_offset >= kLogBlock) return fail(TCRC_ERR_INVALID, "block_offset must be below 32768");
+  if (n == 0) return TCRC_OK;
+  if (!d_src || !h_recs || !d_dst) return fail(TCRC_ERR_INVALID, "null argument");
+  std::vector<Frag> frags;
+  uint32_t bo = 0;
+  uint64_t phys = 0;
+  const uint64_t total = plan_frames(h_recs, n, recycle != 0, block_offset, &frags, &bo, &phys);
+  if (total > dst_capacity) return fail(TCRC_ERR_INVALID, "dst_capacity is smaller than the framed size");
+  if (frags.size() >= (1ull << 32)) return fail(TCRC_ERR_TOO_LARGE, "too many physical records in one call");
+  HIP_TRY(hipSetDevice(ctx->device));
+  std::lock_guard<std::mutex> lock(ctx->wal_mu);
+  hipStream_t s = (hipStream_t)stream;
+  const size_t frag_bytes = frags.size() * sizeof(Frag);
+  const size_t span_off = (frag_bytes + 255) & ~(size_t)255;
+  if (int rc = scratch_reserve(ctx, &ctx->wal_frags, span_off + frags.size() * sizeof(tcrc_desc))) return rc;
+  HIP_TRY(hipMemcpyAsync(ctx->wal_frags.p, frags.data(), frag_bytes, hipMemcpyHostToDevice, s));
+  FrameParams f{};
+  f.src = (const uint8_t*)d_src;
+  f.dst = (uint8_t*)d_dst;
+  f.frags = (const Frag*)ctx->wal_frags.p;
+  f.nfrags = (uint32_t)frags.size();
+  f.header_size = recycle ? kRecyclableHeader : kHeader;
+  f.log_number = (uint32_t)log_number;
+  f.spans = (tcrc_desc*)((uint8_t*)ctx->wal_frags.p + span_off);
+  hipLaunchKernelGGL(k_wal_frame, dim3((f.nfrags + 3u) / 4u), dim3(256), 0, s, f);
+  HIP_TRY(hipGetLastError());
+  BatchParams p{};
+  p.base = f.dst;
+  p.desc = f.spans;
+  p.n = frags.size();
+  p.uniform_suffix = -1;
+  p.flags = TCRC_F_MASK | kFlagStampBefore;  // zero runs have empty spans, which the kernel does not stamp
+  if (int rc = run_batch(ctx, p, stream)) return rc;
+  HIP_TRY(hipStreamSynchronize(s));  // the piece list was copied from pageable memory
+  if (h_written) *h_written = total;
+  if (block_offset_out) *block_offset_out = bo;
+  if (h_physical_records) *h_physical_records = phys;
+  return TCRC_OK;
+}
 
 extern "C" int tcrc_dev_wal_list(tcrc_ctx* ctx, const void* d_img, uint64_t size, uint64_t log_number,
                                  const tcrc_wal_block* d_blocks, tcrc_wal_record* d_records, uint64_t capacity,

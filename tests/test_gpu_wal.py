@@ -157,3 +157,72 @@ def test_record_list_matches_oracle(recycle):
                                            hrec.ctypes.data, total, C.byref(cnt)))
     assert cnt.value == total and (hrec == r).all() and (hblocks == want_blocks).all()
     eng.close()
+
+
+def _oracle_image(records, recycle, log_number, prefix=b""):
+    """Bytes the CPU oracle writer produces for the records (after first writing `prefix` records)."""
+    t = O.OracleLog(recycle=recycle, log_number=log_number)
+    for r in prefix:
+        t.write(r)
+    start = t.written_bytes()
+    for r in records:
+        t.write(r)
+    img = t.contents()
+    t.close()
+    return img[start:], start % 32768
+
+
+@pytest.mark.parametrize("recycle", [False, True])
+def test_device_framing_is_byte_identical_to_the_cpu_writer(recycle):
+    import ctypes as C
+    import gpu_util as G
+    import terarkdb_amd.capi as capi
+    eng = G.engine()
+    rnd = O.Random(301)
+    hs = 11 if recycle else 7
+    lens = [0, 1, 3, 32768 - hs, 32768 - hs + 1, 65536, 100000, 17, 32761, 32762, 5, 2040, 2040, 2040]
+    lens += [rnd.skewed(17) for _ in range(300)]
+    # trailers of every length 0..10 at the end of a block
+    records = []
+    src = O.splitmix((sum(lens) + 64 + 7) // 8 * 8, 77)
+    offs, pos = [], 3  # records start at odd source offsets
+    for ln in lens:
+        offs.append(pos)
+        records.append(src[pos:pos + ln].tobytes())
+        pos += ln
+    want, _ = _oracle_image(records, recycle, 123)
+    dsrc = G.to_dev(src)
+    arr = (capi.Desc * len(lens))()
+    for i, (o, ln) in enumerate(zip(offs, lens)):
+        arr[i].offset, arr[i].len = o, ln
+    size = capi.lib.tcrc_wal_framed_size(arr, len(lens), int(recycle), 0)
+    assert size == len(want)
+    dst = torch.full((size + 100,), 0xAB, dtype=torch.uint8, device="cuda")
+    written, bo, phys = eng.wal_frame(dsrc, offs, lens, 123, recycle, dst)
+    torch.cuda.synchronize()
+    got = dst.cpu().numpy()
+    assert written == size and bo == size % 32768
+    assert got[:size].tobytes() == want
+    assert (got[size:] == 0xAB).all()  # nothing written past the image
+    # the image verifies clean on the device and lists as many physical records as were framed
+    nb = (size + 32767) // 32768
+    blocks = torch.zeros((nb, 4), dtype=torch.int32, device="cuda")
+    counts = torch.zeros(3, dtype=torch.int64, device="cuda")
+    eng.counts_reset(counts)
+    assert eng.wal_verify(dst, size, 123, blocks, counts) == phys
+    assert int(counts.cpu()[0]) == 0
+    # continuing an existing log: frame the second half starting at the block offset the first half left
+    half = len(lens) // 2
+    first_img, _ = _oracle_image(records[:half], recycle, 123)
+    rest_img, start_bo = _oracle_image(records[half:], recycle, 123, prefix=records[:half])
+    w1, bo1, _ = eng.wal_frame(dsrc, offs[:half], lens[:half], 123, recycle, dst)
+    assert (w1, bo1) == (len(first_img), len(first_img) % 32768) and bo1 == start_bo
+    dst2 = torch.zeros(len(rest_img) + 8, dtype=torch.uint8, device="cuda")
+    w2, bo2, _ = eng.wal_frame(dsrc, offs[half:], lens[half:], 123, recycle, dst2, block_offset=bo1)
+    torch.cuda.synchronize()
+    assert w2 == len(rest_img) and dst2.cpu().numpy()[:w2].tobytes() == rest_img
+    assert bo2 == (len(first_img) + len(rest_img)) % 32768
+    # too small a destination is refused before anything runs
+    with pytest.raises(capi.TcrcError):
+        eng.wal_frame(dsrc, offs, lens, 123, recycle, dst[:size - 1])
+    eng.close()
