@@ -93,3 +93,28 @@ def test_dump_wal_host_logic(case_name, tmp_path):
     import wal_dump_cases
     import wal_dump_util
     getattr(wal_dump_cases, case_name)(wal_dump_util.dump_with_oracle, str(tmp_path))
+
+
+@pytest.mark.parametrize("recycle", [False, True])
+def test_framed_size_matches_the_cpu_writer(recycle):
+    """The fragment plan of the device framer (host arithmetic, no GPU) against the oracle writer's file size,
+    from the start of a file and continuing at an arbitrary block offset."""
+    import terarkdb_amd.capi as capi
+    rnd = O.Random(301)
+    hs = 11 if recycle else 7
+    lens = [0, 1, 32768 - hs, 32768 - hs + 1, 65536, 100000, 32761, 32762] + [rnd.skewed(17) for _ in range(400)]
+    t = O.OracleLog(recycle=recycle, log_number=9)
+    sizes = [0]
+    for ln in lens:
+        t.write(b"x" * ln)
+        sizes.append(t.written_bytes())
+    t.close()
+    arr = (capi.Desc * len(lens))()
+    for i, ln in enumerate(lens):
+        arr[i].offset, arr[i].len = 0, ln
+    assert capi.lib.tcrc_wal_framed_size(arr, len(lens), int(recycle), 0) == sizes[-1]
+    for cut in (1, 7, 50, 200, 399):
+        tail = (capi.Desc * (len(lens) - cut))(*list(arr)[cut:])
+        bo = sizes[cut] % 32768
+        assert capi.lib.tcrc_wal_framed_size(tail, len(lens) - cut, int(recycle), bo) == sizes[-1] - sizes[cut]
+    assert capi.lib.tcrc_wal_framed_size(arr, 0, int(recycle), 0) == 0
