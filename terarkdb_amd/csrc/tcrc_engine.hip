@@ -377,6 +377,11 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p) {
       } else {
         const uint32_t result = (p.flags & TCRC_F_MASK) ? masked : crc;
         if (p.out) p.out[buf] = result;
+        if (p.flags & TCRC_F_STORE_AFTER) {
+          uint8_t* t = const_cast<uint8_t*>(p.base) + off + len;
+          if (sfx >= 0) *t++ = (uint8_t)sfx;
+          __builtin_memcpy(t, &result, 4);
+        }
         if ((p.flags & kFlagStampBefore) && len != 0u) {
           // into the record header of a log image being framed (the image is writable there)
           uint8_t* h = const_cast<uint8_t*>(p.base) + off - 6;
@@ -673,6 +678,14 @@ int tcrc_dev_probe_read(tcrc_ctx* ctx, const void* d_base, uint64_t nbytes, uint
   return TCRC_OK;
 }
 
+// Only the documented flag bits may come in through the C ABI (the higher ones are internal).
+static int check_flags(uint32_t flags, uint32_t allowed) {
+  if (flags & ~allowed) return fail(TCRC_ERR_INVALID, "unknown or misplaced flag bits");
+  return TCRC_OK;
+}
+constexpr uint32_t kStampFlags = TCRC_F_MASK | TCRC_F_STORE_AFTER;
+constexpr uint32_t kVerifyFlags = TCRC_F_MASK | TCRC_F_EXPECT_AFTER | TCRC_F_EXPECT_BEFORE;
+
 static int check_uniform(uint64_t n_blocks, uint32_t block_len, uint64_t stride) {
   if (block_len > (1u << 30)) return fail(TCRC_ERR_TOO_LARGE, "block_len above 1 GiB: use the long-buffer entry point");
   if (n_blocks > 1 && stride < block_len) return fail(TCRC_ERR_INVALID, "stride smaller than block_len");
@@ -683,7 +696,8 @@ int tcrc_dev_blocks_stamp(tcrc_ctx* ctx, const void* d_base, uint64_t n_blocks, 
                           uint32_t init, int suffix_byte, const uint8_t* d_suffix, uint32_t flags, uint32_t* d_out,
                           void* stream) {
   if (int rc = check_uniform(n_blocks, block_len, stride)) return rc;
-  if (!d_out && n_blocks) return fail(TCRC_ERR_INVALID, "null output pointer");
+  if (int rc = check_flags(flags, kStampFlags)) return rc;
+  if (!d_out && !(flags & TCRC_F_STORE_AFTER) && n_blocks) return fail(TCRC_ERR_INVALID, "null output pointer");
   BatchParams p{};
   p.base = (const uint8_t*)d_base;
   p.n = n_blocks;
@@ -702,6 +716,7 @@ int tcrc_dev_blocks_verify(tcrc_ctx* ctx, const void* d_base, uint64_t n_blocks,
                            const uint32_t* d_expected, uint32_t* d_out, uint8_t* d_ok, uint64_t* d_counts,
                            void* stream) {
   if (int rc = check_uniform(n_blocks, block_len, stride)) return rc;
+  if (int rc = check_flags(flags, kVerifyFlags)) return rc;
   if (!d_counts) return fail(TCRC_ERR_INVALID, "verify needs a counts block");
   if (!d_expected && !(flags & (TCRC_F_EXPECT_AFTER | TCRC_F_EXPECT_BEFORE)))
     return fail(TCRC_ERR_INVALID, "verify needs d_expected or an in-image expectation flag");
@@ -724,7 +739,9 @@ int tcrc_dev_blocks_verify(tcrc_ctx* ctx, const void* d_base, uint64_t n_blocks,
 
 int tcrc_dev_batch_stamp(tcrc_ctx* ctx, const void* d_base, const tcrc_desc* d_desc, uint64_t n,
                          const uint8_t* d_suffix, uint32_t flags, uint32_t* d_out, void* stream) {
-  if (n && (!d_desc || !d_out)) return fail(TCRC_ERR_INVALID, "null descriptor or output pointer");
+  if (int rc = check_flags(flags, kStampFlags)) return rc;
+  if (n && (!d_desc || (!d_out && !(flags & TCRC_F_STORE_AFTER))))
+    return fail(TCRC_ERR_INVALID, "null descriptor or output pointer");
   BatchParams p{};
   p.base = (const uint8_t*)d_base;
   p.desc = d_desc;
@@ -740,6 +757,7 @@ int tcrc_dev_batch_verify(tcrc_ctx* ctx, const void* d_base, const tcrc_desc* d_
                           const uint8_t* d_suffix, uint32_t flags, const uint32_t* d_expected, uint32_t* d_out,
                           uint8_t* d_ok, uint64_t* d_counts, void* stream) {
   if (n && !d_desc) return fail(TCRC_ERR_INVALID, "null descriptor pointer");
+  if (int rc = check_flags(flags, kVerifyFlags)) return rc;
   if (!d_counts) return fail(TCRC_ERR_INVALID, "verify needs a counts block");
   if (!d_expected && !(flags & (TCRC_F_EXPECT_AFTER | TCRC_F_EXPECT_BEFORE)))
     return fail(TCRC_ERR_INVALID, "verify needs d_expected or an in-image expectation flag");

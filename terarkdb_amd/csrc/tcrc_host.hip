@@ -159,6 +159,7 @@ int tcrc_host_batch_stamp(tcrc_ctx* ctx, const void* h_base, uint64_t base_bytes
   if (!ctx) return fail(TCRC_ERR_INVALID, "null context");
   if (n == 0) return TCRC_OK;
   if (!h_base || !h_desc || !h_out) return fail(TCRC_ERR_INVALID, "null argument");
+  if (flags & TCRC_F_STORE_AFTER) return fail(TCRC_ERR_INVALID, "host entry points return the values: nothing to store into");
   for (uint64_t i = 0; i < n; ++i)
     if (h_desc[i].offset + h_desc[i].len > base_bytes) return fail(TCRC_ERR_INVALID, "descriptor outside the buffer");
   std::lock_guard<std::mutex> lock(ctx->host_mu);
@@ -182,6 +183,7 @@ int tcrc_host_blocks_stamp(tcrc_ctx* ctx, const void* h_base, uint64_t n_blocks,
   if (!ctx) return fail(TCRC_ERR_INVALID, "null context");
   if (n_blocks == 0) return TCRC_OK;
   if (!h_base || !h_out) return fail(TCRC_ERR_INVALID, "null argument");
+  if (flags & TCRC_F_STORE_AFTER) return fail(TCRC_ERR_INVALID, "host entry points return the values: nothing to store into");
   std::lock_guard<std::mutex> lock(ctx->host_mu);
   if (int rc = host_begin(ctx)) return rc;
   const uint64_t bytes = (n_blocks - 1) * stride + block_len;

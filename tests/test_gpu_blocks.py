@@ -162,3 +162,51 @@ def test_verify_counts_and_first_bad(eng):
     torch.cuda.synchronize()
     c = counts.cpu().numpy().view(np.uint64)
     assert int(c[capi.CNT_MISMATCH]) == 3 and int(c[capi.CNT_FIRST_BAD]) == 37
+
+
+def test_trailers_stored_in_place(eng):
+    """TCRC_F_STORE_AFTER writes [type][Mask(crc)] behind every block, like WriteRawBlock appends it
+    (table/block_based_table_builder.cc:626-631), for uniform blocks and for a descriptor list."""
+    import gpu_util as G
+    import terarkdb_amd.capi as capi
+    rng = np.random.default_rng(12)
+    n, blen, stride = 777, 4096, 4101
+    host = O.splitmix((n * stride + 7) // 8 * 8, 91).copy()
+    dev = G.to_dev(host)
+    eng.blocks_stamp(dev, n, blen, stride, None, suffix_byte=1, flags=capi.F_MASK | capi.F_STORE_AFTER)
+    torch.cuda.synchronize()
+    got = dev.cpu().numpy()
+    want = O.sst_trailer_batch(host, blen, stride, n, 1)
+    for i in (0, 1, 400, n - 1):
+        t = got[i * stride + blen: i * stride + blen + 5]
+        assert t[0] == 1 and int(t[1:5].view("<u4")[0]) == int(want[i])
+    img = got[:n * stride].reshape(n, stride)
+    assert (img[:, blen] == 1).all() and (img[:, blen + 1:].copy().view("<u4").reshape(n) == want).all()
+    assert (img[:, :blen] == host[:n * stride].reshape(n, stride)[:, :blen]).all()  # contents untouched
+    # variable-length blocks with per-block type bytes, packed back to back with their trailers
+    lens = rng.integers(1, 9000, 300).astype(np.uint32)
+    types = rng.integers(0, 8, 300).astype(np.uint8)
+    offs = np.concatenate([[0], np.cumsum(lens.astype(np.uint64) + 5)[:-1]]).astype(np.uint64)
+    total = int(offs[-1] + lens[-1] + 5)
+    host2 = O.splitmix((total + 7) // 8 * 8, 92).copy()
+    dev2 = G.to_dev(host2)
+    desc = capi.make_desc_tensor(offs, lens, np.zeros(300, np.uint32), "cuda")
+    out = torch.zeros(300, dtype=torch.int32, device="cuda")
+    eng.batch_stamp(dev2, desc, 300, out, suffix=G.to_dev(types), flags=capi.F_MASK | capi.F_STORE_AFTER)
+    torch.cuda.synchronize()
+    got2 = dev2.cpu().numpy()
+    for i in range(300):
+        o, ln = int(offs[i]), int(lens[i])
+        crc = O.mask(O.extend(O.value(host2[o:o + ln]), bytes([int(types[i])])))
+        assert got2[o + ln] == types[i] and int(got2[o + ln + 1:o + ln + 5].copy().view("<u4")[0]) == crc
+        assert int(out.cpu().numpy().view(np.uint32)[i]) == crc
+    # and the image now verifies with the in-image expectation
+    counts = torch.zeros(capi.CNT_WORDS, dtype=torch.int64, device="cuda")
+    eng.counts_reset(counts)
+    desc_with_type = capi.make_desc_tensor(offs, lens + 1, np.zeros(300, np.uint32), "cuda")  # fetcher's span
+    eng.batch_verify(dev2, desc_with_type, 300, counts, flags=capi.F_EXPECT_AFTER)
+    c = counts.cpu().numpy()
+    assert (int(c[capi.CNT_MISMATCH]), int(c[capi.CNT_CHECKED])) == (0, 300)
+    # internal flag bits are refused at the ABI
+    with pytest.raises(capi.TcrcError):
+        eng.batch_stamp(dev2, desc, 300, out, flags=0x100)
