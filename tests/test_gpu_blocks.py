@@ -210,3 +210,45 @@ def test_trailers_stored_in_place(eng):
     # internal flag bits are refused at the ABI
     with pytest.raises(capi.TcrcError):
         eng.batch_stamp(dev2, desc, 300, out, flags=0x100)
+
+
+def test_batch_entry_points_can_be_captured_in_a_graph():
+    """The batch entry points only enqueue kernels (no allocation, no synchronisation), so a caller with a
+    launch-bound loop can record them into a HIP graph and replay it."""
+    import gpu_util as G
+    import terarkdb_amd.capi as capi
+    eng = G.engine()
+    n, blen = 2000, 4096
+    host = O.splitmix(n * blen, 5)
+    dev = G.to_dev(host)
+    stored = torch.zeros(n, dtype=torch.int32, device="cuda")
+    out = torch.zeros(n, dtype=torch.int32, device="cuda")
+    counts = torch.zeros(capi.CNT_WORDS, dtype=torch.int64, device="cuda")
+    eng.blocks_stamp(dev, n, blen, blen, stored, suffix_byte=0, flags=capi.F_MASK)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):  # warm-up on the capture stream, as graph capture wants
+        eng.counts_reset(counts, stream=side.cuda_stream)
+        eng.blocks_verify(dev, n, blen, blen, counts, expected=stored, out=out, suffix_byte=0, stream=side.cuda_stream)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        s = torch.cuda.current_stream().cuda_stream
+        eng.counts_reset(counts, stream=s)
+        eng.blocks_verify(dev, n, blen, blen, counts, expected=stored, out=out, suffix_byte=0, stream=s)
+    want = O.sst_trailer_batch(host, blen, blen, n, 0)
+    for rep in range(3):
+        out.zero_()
+        if rep == 2:
+            dev[5 * blen + 1] ^= 4  # the graph reads the same buffers: a change in them shows in the replay
+        g.replay()
+        torch.cuda.synchronize()
+        c = counts.cpu().numpy()
+        got = out.cpu().numpy().view(np.uint32)
+        if rep < 2:
+            assert (got == want).all() and int(c[capi.CNT_MISMATCH]) == 0 and int(c[capi.CNT_CHECKED]) == n
+        else:
+            assert int(c[capi.CNT_MISMATCH]) == 1 and int(c[capi.CNT_FIRST_BAD]) == 5
+    eng.close()
