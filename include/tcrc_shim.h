@@ -96,6 +96,15 @@ typedef int (*tcrc_shim_check_fn)(void* user, const void* image, size_t image_by
 int tcrc_shim_sst_verify_cb(tcrc_shim_check_fn fn, void* user, const char* path, size_t extent_bytes, int read_threads,
                             int index_type_hint, uint64_t* stats_out, char* message, size_t message_cap);
 
+/* Table footer (table/format.cc:113-210): encode writes 48 bytes (legacy != 0: no checksum byte, version 0,
+ * legacy magic number) or 53 bytes into out and returns the length; decode takes the tail of a file (at
+ * least its last 48 bytes) and returns 0 or -1 with the Status text in message.  A legacy magic number
+ * comes back up-converted with version 0 and checksum kCRC32c, as the reference reports it. */
+int tcrc_shim_footer_encode(int checksum, uint32_t version, int legacy, uint64_t metaindex_offset,
+                            uint64_t metaindex_size, uint64_t index_offset, uint64_t index_size, uint8_t* out);
+int tcrc_shim_footer_decode(const void* tail, size_t n, int* checksum, uint32_t* version, uint64_t* magic,
+                            uint64_t* handles4, char* message, size_t message_cap);
+
 /* `ldb dump_wal` (tools/ldb_cmd.cc:1967-2037): checks every record of the log file on the GPU, then
  * writes the rows ("Sequence,Count,ByteSize,Physical Offset,Key(s)" ...) to out and the
  * "Corruption detected in log file ..." lines to err, both NUL-terminated and cut at their caps;

@@ -363,6 +363,44 @@ int tcrc_shim_dump_wal_cb(tcrc_shim_scan_fn fn, void* user, const char* path, in
   return DumpWalWith(&verifier, path, print_header, print_values, out, out_cap, out_len, err, err_cap, err_len);
 }
 
+int tcrc_shim_footer_encode(int checksum, uint32_t version, int legacy, uint64_t metaindex_offset,
+                            uint64_t metaindex_size, uint64_t index_offset, uint64_t index_size, uint8_t* out) {
+  Footer f;
+  f.checksum = checksum;
+  f.version = version;
+  f.metaindex_handle.offset = metaindex_offset;
+  f.metaindex_handle.size = metaindex_size;
+  f.index_handle.offset = index_offset;
+  f.index_handle.size = index_size;
+  std::string enc;
+  f.EncodeTo(&enc, legacy != 0);
+  memcpy(out, enc.data(), enc.size());
+  return static_cast<int>(enc.size());
+}
+
+int tcrc_shim_footer_decode(const void* tail, size_t n, int* checksum, uint32_t* version, uint64_t* magic,
+                            uint64_t* handles4, char* message, size_t message_cap) {
+  Status s;
+  Footer f;
+  if (n < Footer::kMinEncodedLength) {
+    s = Status::Corruption("input is too short to be an sstable");
+  } else {
+    Slice in(static_cast<const char*>(tail), n);
+    s = f.DecodeFrom(&in);
+  }
+  if (checksum) *checksum = f.checksum;
+  if (version) *version = f.version;
+  if (magic) *magic = f.table_magic_number;
+  if (handles4) {
+    handles4[0] = f.metaindex_handle.offset;
+    handles4[1] = f.metaindex_handle.size;
+    handles4[2] = f.index_handle.offset;
+    handles4[3] = f.index_handle.size;
+  }
+  if (message && message_cap) snprintf(message, message_cap, "%s", s.ToString().c_str());
+  return s.ok() ? 0 : -1;
+}
+
 int tcrc_shim_file_checksum(tcrc_ctx* ctx, const char* path, uint64_t size_limit, size_t buffer_size,
                             uint32_t* checksum_out, uint64_t* size_out, char* message, size_t message_cap) {
   uint32_t crc = 0;
