@@ -21,7 +21,10 @@ def engine(lanes=None):
 
 
 def to_dev(a):
-    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    a = np.ascontiguousarray(a)
+    if not a.flags.writeable:
+        a = a.copy()  # torch refuses to wrap read-only memory quietly
+    return torch.from_numpy(a).cuda()
 
 
 def splitmix_dev(nbytes, state=301):

@@ -117,3 +117,52 @@ def test_descriptors_past_four_gib(shard):
     got2 = out2.cpu().numpy().view(np.uint32)
     for i in range(2):
         assert int(got2[i]) == O.extend(li[i], data[lo[i]:lo[i] + ll[i]].cpu().numpy().tobytes())
+
+
+def test_log_image_larger_than_one_scan_slice():
+    """A 9 GiB log image (the scan works in slices of 8 GiB): a block-aligned log piece tiled on the device.
+    Per-block results must repeat the oracle's results for the piece; one corruption sits in the last slice."""
+    import gpu_util as G
+    import terarkdb_amd.capi as capi
+    t = O.OracleLog(recycle=False, log_number=7)
+    rnd = O.Random(17)
+    while t.written_bytes() < 3 * (1 << 20):
+        t.write(O.big_string(b"%d." % t.written_bytes(), rnd.skewed(14)))
+    room = 32768 - t.written_bytes() % 32768
+    if room < 7:  # only a trailer is left: it is zero-filled by the next record, which we make end the block
+        t.write(b"")
+        room = 32768 - t.written_bytes() % 32768
+    t.write(b"z" * (room - 7))
+    piece = np.frombuffer(t.contents(), dtype=np.uint8)
+    t.close()
+    assert piece.size % 32768 == 0
+    want_piece = O.wal_scan_blocks(piece, 7)
+    reps = (9 * GIB) // piece.size + 1
+    dev = G.to_dev(piece).repeat(reps)
+    size = dev.numel()
+    assert size > 8 * GIB + 32768
+    nb_piece = piece.size // 32768
+    nb = size // 32768
+    bad_block = nb - 3  # in the second slice
+    recs, _ = O.list_physical(piece.tobytes(), 7)
+    in_blk = [r for r in recs if int(r[0]) // 32768 == bad_block % nb_piece]
+    victim = in_blk[min(1, len(in_blk) - 1)]
+    pos = (bad_block // nb_piece) * piece.size + int(victim[0]) + 7  # first payload byte of that record
+    dev[pos] ^= 0x40
+    eng = G.engine()
+    blocks = torch.zeros((nb, 4), dtype=torch.int32, device="cuda")
+    counts = torch.zeros(3, dtype=torch.int64, device="cuda")
+    eng.counts_reset(counts)
+    n = eng.wal_verify(dev, size, 7, blocks, counts)
+    torch.cuda.synchronize()
+    got = blocks.cpu().numpy().view(np.uint32).reshape(reps, nb_piece, 4)
+    want = np.broadcast_to(want_piece, (reps, nb_piece, 4)).copy()
+    want[bad_block // nb_piece, bad_block % nb_piece, 1] = min(1, len(in_blk) - 1)
+    assert (got == want).all()
+    assert n == reps * int(want_piece[:, 0].sum())
+    c = counts.cpu().numpy().view(np.uint64)
+    assert int(c[capi.CNT_MISMATCH]) == 1 and int(c[capi.CNT_FIRST_BAD]) == bad_block
+    assert int(c[capi.CNT_CHECKED]) == n
+    eng.close()
+    del dev
+    torch.cuda.empty_cache()

@@ -226,3 +226,34 @@ def test_device_framing_is_byte_identical_to_the_cpu_writer(recycle):
     with pytest.raises(capi.TcrcError):
         eng.wal_frame(dsrc, offs, lens, 123, recycle, dst[:size - 1])
     eng.close()
+
+
+def test_scan_of_garbage_and_preallocated_images_matches_oracle():
+    """Images that are not logs at all: random bytes, zeros (a preallocated file), a valid log followed by
+    zeros and by random bytes, odd sizes.  The structural walk must end every block where the CPU rules do."""
+    import gpu_util as G
+    eng = G.engine()
+    rng = np.random.default_rng(99)
+    good = np.frombuffer(O.build_wal_image(False, n_random=60, seed=3), dtype=np.uint8)
+    images = [
+        rng.integers(0, 256, (1 << 20) + 13, dtype=np.uint8),
+        np.zeros(5 * 32768 + 100, dtype=np.uint8),
+        np.concatenate([good, np.zeros(70000, dtype=np.uint8)]),
+        np.concatenate([good, rng.integers(0, 256, 70001, dtype=np.uint8)]),
+        rng.integers(0, 256, 6, dtype=np.uint8),          # shorter than a header
+        rng.integers(0, 9, 300000, dtype=np.uint8),       # small values: plausible types and short lengths
+    ]
+    for k, img in enumerate(images):
+        for log_number in (123, 0, int(img[7]) if img.size > 7 else 1):
+            want = O.wal_scan_blocks(img, log_number)
+            dev = G.to_dev(img)
+            nb = (img.size + 32767) // 32768
+            blocks = torch.zeros((nb, 4), dtype=torch.int32, device="cuda")
+            counts = torch.zeros(3, dtype=torch.int64, device="cuda")
+            eng.counts_reset(counts)
+            n = eng.wal_verify(dev, img.size, log_number, blocks, counts)
+            torch.cuda.synchronize()
+            got = blocks.cpu().numpy().view(np.uint32)
+            assert (got == want).all(), (k, log_number, np.nonzero((got != want).any(axis=1))[0][:5])
+            assert n == int(want[:, 0].sum())
+    eng.close()
