@@ -53,7 +53,12 @@ void tcrc_shim_wal_writer_free(void* w);
 void* tcrc_shim_wal_reader_new(tcrc_ctx* ctx, void* memfile, int checksum, uint64_t log_number, int retry_after_eof);
 void* tcrc_shim_wal_reader_new_cb(tcrc_shim_scan_fn fn, void* user, void* memfile, int checksum, uint64_t log_number,
                                   int retry_after_eof);
-void* tcrc_shim_wal_reader_open(tcrc_ctx* ctx, const char* path, int checksum, uint64_t log_number);
+/* Readers over a real file (POSIX sequential reads).  With retry_after_eof the reader keeps polling the
+ * file for the rest of a record that is still being written (db/log_reader.cc:294-296), as a tailing
+ * reader does. */
+void* tcrc_shim_wal_reader_open(tcrc_ctx* ctx, const char* path, int checksum, uint64_t log_number, int retry_after_eof);
+void* tcrc_shim_wal_reader_open_cb(tcrc_shim_scan_fn fn, void* user, const char* path, int checksum,
+                                   uint64_t log_number, int retry_after_eof);
 /* Verifies img[0..n) (or, with img == NULL, the in-memory file's present contents) in one
  * pass and attaches the verdicts, so ReadRecord does not ask block by block. */
 int tcrc_shim_wal_reader_attach_image(void* r, const void* img, size_t n);

@@ -89,7 +89,8 @@ SIGNATURES.update({
     "tcrc_shim_wal_writer_free": (None, [_vp]),
     "tcrc_shim_wal_reader_new": (_vp, [_vp, _vp, _i, _u64, _i]),
     "tcrc_shim_wal_reader_new_cb": (_vp, [SCAN_FN, _vp, _vp, _i, _u64, _i]),
-    "tcrc_shim_wal_reader_open": (_vp, [_vp, C.c_char_p, _i, _u64]),
+    "tcrc_shim_wal_reader_open": (_vp, [_vp, C.c_char_p, _i, _u64, _i]),
+    "tcrc_shim_wal_reader_open_cb": (_vp, [SCAN_FN, _vp, C.c_char_p, _i, _u64, _i]),
     "tcrc_shim_wal_reader_attach_image": (_i, [_vp, _vp, _sz]),
     "tcrc_shim_wal_reader_read_record": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_sz)]),
     "tcrc_shim_wal_reader_dropped_bytes": (_sz, [_vp]),

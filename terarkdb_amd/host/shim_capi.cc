@@ -178,14 +178,29 @@ void* tcrc_shim_wal_reader_new_cb(tcrc_shim_scan_fn fn, void* user, void* memfil
                      log_number, retry_after_eof);
 }
 
-void* tcrc_shim_wal_reader_open(tcrc_ctx* ctx, const char* path, int checksum, uint64_t log_number) {
+namespace {
+void* open_reader(std::unique_ptr<log::RecordVerifier> verifier, const char* path, int checksum, uint64_t log_number,
+                  int retry_after_eof) {
   std::unique_ptr<SequentialFile> f;
   if (!NewPosixSequentialFile(path, &f).ok()) return nullptr;
   ReaderBox* b = new ReaderBox();
-  b->verifier.reset(new log::DeviceRecordVerifier(ctx));
+  b->verifier = std::move(verifier);
   b->log_number = log_number;
-  b->reader.reset(new log::Reader(std::move(f), &b->report, checksum != 0, log_number, false, b->verifier.get()));
+  b->reader.reset(new log::Reader(std::move(f), &b->report, checksum != 0, log_number, retry_after_eof != 0,
+                                  b->verifier.get()));
   return b;
+}
+}  // namespace
+
+void* tcrc_shim_wal_reader_open(tcrc_ctx* ctx, const char* path, int checksum, uint64_t log_number, int retry_after_eof) {
+  return open_reader(std::unique_ptr<log::RecordVerifier>(new log::DeviceRecordVerifier(ctx)), path, checksum,
+                     log_number, retry_after_eof);
+}
+
+void* tcrc_shim_wal_reader_open_cb(tcrc_shim_scan_fn fn, void* user, const char* path, int checksum,
+                                   uint64_t log_number, int retry_after_eof) {
+  return open_reader(std::unique_ptr<log::RecordVerifier>(new CallbackVerifier(fn, user)), path, checksum, log_number,
+                     retry_after_eof);
 }
 
 int tcrc_shim_wal_reader_attach_image(void* r, const void* img, size_t n) {

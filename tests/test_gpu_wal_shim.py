@@ -165,3 +165,18 @@ def test_dump_wal_on_device(case_name, tmp_path):
         getattr(wal_dump_cases, case_name)(wal_dump_util.dump_with_engine(e), str(tmp_path))
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("recycle", [False, True])
+@pytest.mark.parametrize("case_name", ["partial_header", "full_header", "later_in_the_file"])
+def test_tailing_reader_on_device(case_name, recycle, tmp_path):
+    import gpu_util as G
+    import terarkdb_amd.capi as capi
+    import wal_tail_cases
+    e = G.engine()
+    try:
+        def open_reader(path, log_number):
+            return capi.lib.tcrc_shim_wal_reader_open(e.ctx, path.encode(), 1, log_number, 1)
+        getattr(wal_tail_cases, case_name)(open_reader, str(tmp_path), recycle)
+    finally:
+        e.close()

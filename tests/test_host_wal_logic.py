@@ -118,3 +118,15 @@ def test_framed_size_matches_the_cpu_writer(recycle):
         bo = sizes[cut] % 32768
         assert capi.lib.tcrc_wal_framed_size(tail, len(lens) - cut, int(recycle), bo) == sizes[-1] - sizes[cut]
     assert capi.lib.tcrc_wal_framed_size(arr, 0, int(recycle), 0) == 0
+
+
+@pytest.mark.parametrize("recycle", [False, True])
+@pytest.mark.parametrize("case_name", ["partial_header", "full_header", "later_in_the_file"])
+def test_tailing_reader_host_logic(case_name, recycle, tmp_path):
+    import engine_log
+    import terarkdb_amd.capi as capi
+    import wal_tail_cases
+
+    def open_reader(path, log_number):
+        return capi.lib.tcrc_shim_wal_reader_open_cb(engine_log._oracle_scan, None, path.encode(), 1, log_number, 1)
+    getattr(wal_tail_cases, case_name)(open_reader, str(tmp_path), recycle)
