@@ -65,6 +65,23 @@ const char* tcrc_last_error(void);
 /* Text like the reference's IsFastCrc32Supported() (util/crc32c.cc:445-481). */
 const char* tcrc_describe(tcrc_ctx* ctx);
 
+/* Running totals of one context: the engine's counterpart of the reference's block_checksum_time perf
+ * counter (table/block_fetcher.cc:40) and WAL/ SST tickers (monitoring/statistics.cc).  All values only grow
+ * until tcrc_reset_stats. */
+typedef struct tcrc_stats {
+  uint64_t batch_launches; /* launches of the batch CRC kernel */
+  uint64_t batch_buffers;  /* buffers handed to it (the capacity, for lists counted on the device) */
+  uint64_t host_calls;     /* calls of the host-pointer entry points (tcrc_host_*, tcrc_extend, tcrc_value) */
+  uint64_t host_bytes_in;  /* bytes they copied to the device */
+  uint64_t host_nanos;     /* wall time spent inside them */
+  uint64_t log_images;     /* log images scanned (tcrc_dev_wal_verify) */
+  uint64_t log_bytes;      /* and their bytes */
+  uint64_t long_calls;     /* tcrc_dev_extend_long calls */
+  uint64_t long_bytes;     /* and the bytes they covered */
+} tcrc_stats;
+int tcrc_get_stats(tcrc_ctx* ctx, tcrc_stats* out);
+int tcrc_reset_stats(tcrc_ctx* ctx);
+
 /* ---- scalar helpers (host arithmetic on 32-bit values only) ------------------ */
 /* util/crc32c.h:38-47 */
 uint32_t tcrc_mask(uint32_t crc);

@@ -31,6 +31,11 @@ class WalBlock(C.Structure):
                 ("end_code", C.c_uint32)]
 
 
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("batch_launches", "batch_buffers", "host_calls", "host_bytes_in", "host_nanos",
+                                          "log_images", "log_bytes", "long_calls", "long_bytes")]
+
+
 class Desc(C.Structure):
     _fields_ = [("offset", C.c_uint64), ("len", C.c_uint32), ("init", C.c_uint32)]
 
@@ -68,6 +73,8 @@ SIGNATURES.update({
     "tcrc_wal_framed_size": (_u64, [_vp, _u64, _i, _u32]),
     "tcrc_dev_wal_list": (_i, [_vp, _vp, _u64, _u64, _vp, _vp, _u64, C.POINTER(_u64), _vp]),
     "tcrc_host_wal_list": (_i, [_vp, _vp, _u64, _u64, _vp, _vp, _u64, C.POINTER(_u64)]),
+    "tcrc_get_stats": (_i, [_vp, C.POINTER(Stats)]),
+    "tcrc_reset_stats": (_i, [_vp]),
     "tcrc_debug_tables": (_i, [_i, _vp, _vp, _sz, C.POINTER(_sz)]),
     "tcrc_extend": (_i, [_vp, _u32, _vp, _sz, C.POINTER(_u32)]),
     "tcrc_value": (_i, [_vp, _vp, _sz, C.POINTER(_u32)]),
@@ -228,6 +235,11 @@ class Engine:
 
     def value(self, data):
         return self.extend(0, data)
+
+    def stats(self):
+        st = Stats()
+        check(lib.tcrc_get_stats(self.ctx, C.byref(st)))
+        return {n: getattr(st, n) for n, _ in Stats._fields_}
 
     def counts_reset(self, counts, stream=None):
         check(lib.tcrc_dev_counts_reset(self.ctx, _dp(counts), self._stream(stream)))

@@ -555,6 +555,8 @@ int run_batch(tcrc_ctx* ctx, BatchParams p, void* stream) {
       else if (p.n <= waves * 4) g = 16;
     }
   }
+  ctx->st_batch_launches.fetch_add(1, std::memory_order_relaxed);
+  ctx->st_batch_buffers.fetch_add(p.n, std::memory_order_relaxed);
   switch (g) {
     case 4: return launch_batch<4>(ctx, p, s);
     case 8: return launch_batch<8>(ctx, p, s);
@@ -649,6 +651,29 @@ int tcrc_shutdown(tcrc_ctx* ctx) {
   for (hipEvent_t ev : ctx->stage_done)
     if (ev) (void)hipEventDestroy(ev);
   delete ctx;
+  return TCRC_OK;
+}
+
+int tcrc_get_stats(tcrc_ctx* ctx, tcrc_stats* out) {
+  if (!ctx || !out) return fail(TCRC_ERR_INVALID, "null argument");
+  out->batch_launches = ctx->st_batch_launches.load();
+  out->batch_buffers = ctx->st_batch_buffers.load();
+  out->host_calls = ctx->st_host_calls.load();
+  out->host_bytes_in = ctx->st_host_bytes_in.load();
+  out->host_nanos = ctx->st_host_nanos.load();
+  out->log_images = ctx->st_log_images.load();
+  out->log_bytes = ctx->st_log_bytes.load();
+  out->long_calls = ctx->st_long_calls.load();
+  out->long_bytes = ctx->st_long_bytes.load();
+  return TCRC_OK;
+}
+
+int tcrc_reset_stats(tcrc_ctx* ctx) {
+  if (!ctx) return fail(TCRC_ERR_INVALID, "null context");
+  for (std::atomic<uint64_t>* a : {&ctx->st_batch_launches, &ctx->st_batch_buffers, &ctx->st_host_calls,
+                                   &ctx->st_host_bytes_in, &ctx->st_host_nanos, &ctx->st_log_images, &ctx->st_log_bytes,
+                                   &ctx->st_long_calls, &ctx->st_long_bytes})
+    a->store(0);
   return TCRC_OK;
 }
 

@@ -92,6 +92,7 @@ int staged_upload(tcrc_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
 
 int upload(tcrc_ctx* ctx, tcrc_scratch* s, const void* h, size_t bytes, size_t slack = 64) {
   if (int rc = scratch_reserve(ctx, s, bytes + slack)) return rc;
+  ctx->st_host_bytes_in.fetch_add(bytes, std::memory_order_relaxed);
   if (bytes >= ((size_t)16 << 20) && !is_pinned(h)) return staged_upload(ctx, s->p, h, bytes);
   if (bytes) HIP_TRY(hipMemcpyAsync(s->p, h, bytes, hipMemcpyHostToDevice, ctx->host_stream));
   return TCRC_OK;
@@ -162,6 +163,7 @@ int tcrc_host_batch_stamp(tcrc_ctx* ctx, const void* h_base, uint64_t base_bytes
   if (flags & TCRC_F_STORE_AFTER) return fail(TCRC_ERR_INVALID, "host entry points return the values: nothing to store into");
   for (uint64_t i = 0; i < n; ++i)
     if (h_desc[i].offset + h_desc[i].len > base_bytes) return fail(TCRC_ERR_INVALID, "descriptor outside the buffer");
+  HostCallTimer timer(ctx);
   std::lock_guard<std::mutex> lock(ctx->host_mu);
   if (int rc = host_begin(ctx)) return rc;
   if (int rc = upload(ctx, &ctx->host_data, h_base, base_bytes)) return rc;
@@ -184,6 +186,7 @@ int tcrc_host_blocks_stamp(tcrc_ctx* ctx, const void* h_base, uint64_t n_blocks,
   if (n_blocks == 0) return TCRC_OK;
   if (!h_base || !h_out) return fail(TCRC_ERR_INVALID, "null argument");
   if (flags & TCRC_F_STORE_AFTER) return fail(TCRC_ERR_INVALID, "host entry points return the values: nothing to store into");
+  HostCallTimer timer(ctx);
   std::lock_guard<std::mutex> lock(ctx->host_mu);
   if (int rc = host_begin(ctx)) return rc;
   const uint64_t bytes = (n_blocks - 1) * stride + block_len;
@@ -214,6 +217,7 @@ int tcrc_host_batch_verify(tcrc_ctx* ctx, const void* h_base, uint64_t base_byte
     if ((flags & TCRC_F_EXPECT_BEFORE) && h_desc[i].offset < 6)
       return fail(TCRC_ERR_INVALID, "descriptor leaves no room for the stored checksum before it");
   }
+  HostCallTimer timer(ctx);
   std::lock_guard<std::mutex> lock(ctx->host_mu);
   if (int rc = host_begin(ctx)) return rc;
   if (int rc = upload(ctx, &ctx->host_data, h_base, base_bytes)) return rc;
@@ -250,6 +254,7 @@ int tcrc_host_wal_verify(tcrc_ctx* ctx, const void* h_img, uint64_t size, uint64
   }
   if (size == 0) return TCRC_OK;
   if (!h_img || !h_blocks) return fail(TCRC_ERR_INVALID, "null argument");
+  HostCallTimer timer(ctx);
   std::lock_guard<std::mutex> lock(ctx->host_mu);
   if (int rc = host_begin(ctx)) return rc;
   const uint64_t nblocks = (size + 32767) / 32768;
@@ -273,6 +278,7 @@ int tcrc_host_wal_list(tcrc_ctx* ctx, const void* h_img, uint64_t size, uint64_t
   if (h_count) *h_count = 0;
   if (size == 0) return TCRC_OK;
   if (!h_img || (capacity && !h_records)) return fail(TCRC_ERR_INVALID, "null argument");
+  HostCallTimer timer(ctx);
   std::lock_guard<std::mutex> lock(ctx->host_mu);
   if (int rc = host_begin(ctx)) return rc;
   const uint64_t nblocks = (size + 32767) / 32768;
@@ -306,6 +312,7 @@ int tcrc_extend(tcrc_ctx* ctx, uint32_t init, const void* h_data, size_t n, uint
   *out = init;  // Extend over no bytes leaves the value as it is
   if (n == 0) return TCRC_OK;
   if (!h_data) return fail(TCRC_ERR_INVALID, "null argument");
+  HostCallTimer timer(ctx);
   std::lock_guard<std::mutex> lock(ctx->host_mu);
   if (int rc = host_begin(ctx)) return rc;
   // Pieces of up to 256 MiB, chained through init like the callers that feed a file through

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <utility>
@@ -95,6 +97,9 @@ struct tcrc_ctx {
   static constexpr size_t kStageSlotBytes = (size_t)4 << 20;
   char* stage_ring = nullptr;  // kStageSlots * kStageSlotBytes of pinned memory
   hipEvent_t stage_done[kStageSlots] = {};
+  // running totals (tcrc_get_stats)
+  std::atomic<uint64_t> st_batch_launches{0}, st_batch_buffers{0}, st_host_calls{0}, st_host_bytes_in{0},
+      st_host_nanos{0}, st_log_images{0}, st_log_bytes{0}, st_long_calls{0}, st_long_bytes{0};
   // Pinned host buffers handed back through tcrc_host_free, kept for the next tcrc_host_alloc:
   // pinning memory costs about as much as copying it, and callers allocate staging per call.
   std::mutex pin_mu;
@@ -104,6 +109,20 @@ struct tcrc_ctx {
 };
 
 namespace tcrc_internal {
+// Adds one host-pointer call and its wall time to the context's totals when it goes out of scope.
+struct HostCallTimer {
+  tcrc_ctx* ctx;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  explicit HostCallTimer(tcrc_ctx* c) : ctx(c) {}
+  ~HostCallTimer() {
+    if (!ctx) return;
+    ctx->st_host_calls.fetch_add(1, std::memory_order_relaxed);
+    ctx->st_host_nanos.fetch_add(
+        (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(),
+        std::memory_order_relaxed);
+  }
+};
+
 // Makes sure s holds at least `bytes` of device memory on the context's GPU.
 int scratch_reserve(tcrc_ctx* ctx, tcrc_scratch* s, size_t bytes);
 void scratch_release(tcrc_scratch* s);

@@ -120,6 +120,8 @@ extern "C" int tcrc_dev_extend_long(tcrc_ctx* ctx, const void* d_base, const tcr
   if (nseg >= (1ull << 31)) return fail(TCRC_ERR_TOO_LARGE, "too many segments");
 
   std::lock_guard<std::mutex> lock(ctx->long_mu);
+  ctx->st_long_calls.fetch_add(1, std::memory_order_relaxed);
+  ctx->st_long_bytes.fetch_add(total, std::memory_order_relaxed);
   if (int rc = ensure_pow_table(ctx, seg, (uint32_t)((longest + seg - 1) / seg + 1), s)) return rc;
   const size_t in_bytes = n * sizeof(tcrc_desc) + (n + 1) * 4;
   if (int rc = scratch_reserve(ctx, &ctx->long_in, in_bytes)) return rc;

@@ -447,6 +447,8 @@ extern "C" int tcrc_dev_wal_verify(tcrc_ctx* ctx, const void* d_img, uint64_t si
   if (!d_img || !d_blocks || !d_counts) return fail(TCRC_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(ctx->device));
   std::lock_guard<std::mutex> lock(ctx->wal_mu);  // the descriptor scratch belongs to one scan at a time
+  ctx->st_log_images.fetch_add(1, std::memory_order_relaxed);
+  ctx->st_log_bytes.fetch_add(size, std::memory_order_relaxed);
   hipStream_t s = (hipStream_t)stream;
   const uint64_t nblocks_total = (size + kLogBlock - 1) / kLogBlock;
   // One slice is up to 8 GiB (the walk is latency-bound, so fewer, larger launches are cheaper).

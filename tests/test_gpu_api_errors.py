@@ -73,3 +73,31 @@ def test_bad_arguments_and_empty_batches():
                           None, True)
     assert (out.cpu().numpy().view(np.uint32) == want).all()
     eng.close()
+
+
+def test_running_totals():
+    """tcrc_get_stats counts what went through a context."""
+    import gpu_util as G
+    import terarkdb_amd.capi as capi
+    eng = G.engine()
+    assert all(v == 0 for v in eng.stats().values())
+    host = O.splitmix(64 * 4096, 3)
+    dev = G.to_dev(host)
+    out = torch.zeros(64, dtype=torch.int32, device="cuda")
+    eng.blocks_stamp(dev, 64, 4096, 4096, out, flags=capi.F_MASK)
+    eng.blocks_stamp(dev, 32, 4096, 4096, out, flags=capi.F_MASK)
+    eng.extend_long(dev, [0], [200000], [0], out)
+    assert eng.extend(0, host[:1000]) == O.value(host[:1000])
+    img = np.frombuffer(O.build_wal_image(False, n_random=20, edge=False), dtype=np.uint8)
+    blocks = torch.zeros(((img.size + 32767) // 32768, 4), dtype=torch.int32, device="cuda")
+    counts = torch.zeros(3, dtype=torch.int64, device="cuda")
+    eng.counts_reset(counts)
+    eng.wal_verify(G.to_dev(img), img.size, 123, blocks, counts)
+    st = eng.stats()
+    assert st["batch_launches"] >= 6 and st["batch_buffers"] >= 64 + 32
+    assert (st["long_calls"], st["long_bytes"]) == (1, 200000)
+    assert (st["log_images"], st["log_bytes"]) == (1, img.size)
+    assert st["host_calls"] == 1 and st["host_bytes_in"] == 1000 and st["host_nanos"] > 0
+    assert capi.lib.tcrc_reset_stats(eng.ctx) == 0
+    assert all(v == 0 for v in eng.stats().values())
+    eng.close()
