@@ -470,6 +470,22 @@ Status VerifySstFileChecksum(BlockBatchChecker* checker, const RandomAccessFile*
   if (r.options.extent_bytes < (1u << 20)) r.options.extent_bytes = 1u << 20;
   if (stats) stats->file_size = r.file_size;
 
+  // Tables of the reference's other formats are not this driver's: say so before the block-based
+  // open below would call their magic numbers corrupt (table/plain_table_builder.cc:53-54,
+  // table/cuckoo_table_builder.cc:50, table/terark_zip_table.cc:64).
+  if (r.file_size >= 8) {
+    char tail[8];
+    Slice m;
+    Status ms = file->Read(r.file_size - 8, 8, &m, tail);
+    if (ms.ok() && m.size() == 8) {
+      const uint64_t magic = static_cast<uint64_t>(DecodeFixed32(m.data())) |
+                             (static_cast<uint64_t>(DecodeFixed32(m.data() + 4)) << 32);
+      if (magic == 0x8242229663bf9564ull || magic == 0x4f3418eb7a8f13b8ull || magic == 0x926789d0c5f17873ull ||
+          magic == 0x1122334455667788ull)
+        return Status::NotSupported("not a block-based table (plain, cuckoo or TerarkZip format): " + file_name);
+    }
+  }
+
   // BlockBasedTable::Open (table/block_based_table_reader.cc:814-823)
   Footer footer;
   Status s = ReadFooterFromFile(file, r.file_size, file_name, &footer, kBlockBasedTableMagicNumber);

@@ -100,6 +100,14 @@ def structural_errors(verify, tmp):
     rc, msg, _ = verify(lay.path)
     assert rc == 1 and msg.startswith("Corruption: Bad table magic number: expected 9863518390377041911, found ")
     assert msg.endswith(" in " + lay.path)
+    # the reference's other table formats are declined, not called corrupt
+    for magic in (0x8242229663bf9564, 0x4f3418eb7a8f13b8, 0x926789d0c5f17873, 0x1122334455667788):
+        lay = S.build_table(os.path.join(tmp, "other.sst"), n_data=3)
+        raw = bytearray(open(lay.path, "rb").read())
+        raw[-8:] = magic.to_bytes(8, "little")
+        open(lay.path, "wb").write(raw)
+        rc, msg, _ = verify(lay.path)
+        assert rc == 2 and msg.startswith("Not implemented: not a block-based table"), msg
     # unknown footer version
     lay = S.build_table(os.path.join(tmp, "ver.sst"), format_version=9)
     rc, msg, _ = verify(lay.path)
