@@ -120,6 +120,15 @@ int tcrc_shim_dump_wal(tcrc_ctx* ctx, const char* path, int print_header, int pr
 int tcrc_shim_dump_wal_cb(tcrc_shim_scan_fn fn, void* user, const char* path, int print_header, int print_values,
                           char* out, size_t out_cap, size_t* out_len, char* err, size_t err_cap, size_t* err_len);
 
+/* File-level DBImpl::VerifyChecksum (db/db_impl.cc:4657-4690) over a database directory: every NNNNNN.sst in
+ * file-number order (stopping at the first corrupt one, whose name goes to bad_file and whose status to
+ * message), then a checksum scan of NNNNNN.log and MANIFEST-NNNNNN.  Files are dealt to shard_index of
+ * shard_count by position (one shard per GPU).  report_out (may be NULL) receives 8 values: table files
+ * verified, table files declined, table blocks, table bytes covered, log files, log bytes, log records, log
+ * records with a checksum mismatch.  Returns 0 OK, 1 Corruption, -1 other errors. */
+int tcrc_shim_verify_db(tcrc_ctx* ctx, const char* dir, uint32_t shard_index, uint32_t shard_count, uint64_t* report_out,
+                        char* message, size_t message_cap, char* bad_file, size_t bad_file_cap);
+
 /* Whole-file crc32c as the backup engine computes it (utilities/backupable/backupable_db.cc:1414-1452
  * CalculateChecksum; :1195-1283 CopyOrCreateFile): size_limit 0 = whole file; buffer_size 0 = default.
  * Return 0, or -1 with the Status text in message (if not NULL). */

@@ -121,6 +121,7 @@ SIGNATURES.update({
                                    C.POINTER(_sz)]),
     "tcrc_shim_footer_encode": (_i, [_i, _u32, _i, _u64, _u64, _u64, _u64, _vp]),
     "tcrc_shim_footer_decode": (_i, [_vp, _sz, C.POINTER(_i), C.POINTER(_u32), C.POINTER(_u64), _vp, C.c_char_p, _sz]),
+    "tcrc_shim_verify_db": (_i, [_vp, C.c_char_p, _u32, _u32, C.POINTER(_u64), C.c_char_p, _sz, C.c_char_p, _sz]),
     "tcrc_shim_file_checksum": (_i, [_vp, C.c_char_p, _u64, _sz, C.POINTER(_u32), C.POINTER(_u64), C.c_char_p, _sz]),
     "tcrc_shim_copy_file": (_i, [_vp, C.c_char_p, C.c_char_p, _u64, _sz, _i, C.POINTER(_u32), C.POINTER(_u64),
                                  C.c_char_p, _sz]),

@@ -1,0 +1,124 @@
+#include "db_verify.h"
+
+#include <dirent.h>
+#include <errno.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <memory>
+
+#include "wal_dump.h"
+
+namespace terarkdb_amd {
+
+namespace {
+
+struct Named {
+  uint64_t number;
+  std::string path;
+  bool operator<(const Named& o) const { return number != o.number ? number < o.number : path < o.path; }
+};
+
+// NNNNNN<suffix> -> number (util/filename.cc:306-343); false for other names
+bool NumberedName(const std::string& name, const char* suffix, uint64_t* number) {
+  size_t i = 0;
+  uint64_t n = 0;
+  for (; i < name.size() && name[i] >= '0' && name[i] <= '9'; ++i) n = n * 10 + static_cast<uint64_t>(name[i] - '0');
+  if (i == 0 || name.compare(i, std::string::npos, suffix) != 0) return false;
+  *number = n;
+  return true;
+}
+
+Status ScanLogFile(tcrc_ctx* ctx, const std::string& path, DbVerifyReport* report) {
+  std::unique_ptr<RandomAccessFile> file;
+  Status s = NewPosixRandomAccessFile(path, &file);
+  if (!s.ok()) return s;
+  const size_t size = static_cast<size_t>(file->Size());
+  ++report->log_files;
+  report->log_bytes += size;
+  if (size == 0) return Status::OK();
+  char* img = static_cast<char*>(tcrc_host_alloc(ctx, size));
+  if (!img) return Status::IOError("checksum engine: cannot allocate pinned memory for " + path);
+  s = ParallelRead(file.get(), 0, size, img, 8);
+  std::vector<tcrc_wal_block> blocks((size + log::kBlockSize - 1) / log::kBlockSize);
+  uint64_t counts[TCRC_CNT_WORDS] = {0, 0, 0}, records = 0;
+  if (s.ok() && tcrc_host_wal_verify(ctx, img, size, LogNumberFromFileName(path), blocks.data(), counts, &records) != TCRC_OK)
+    s = Status::IOError(std::string("checksum engine: ") + tcrc_last_error());
+  tcrc_host_free(ctx, img);
+  if (!s.ok()) return s;
+  report->log_records += records;
+  report->log_bad_records += counts[TCRC_CNT_MISMATCH];
+  const tcrc_wal_block& tail = blocks.back();
+  const bool torn = tail.end_code == TCRC_WAL_END_SHORT_AT_EOF || tail.end_code == TCRC_WAL_END_BAD_LEN_AT_EOF;
+  if (counts[TCRC_CNT_MISMATCH] || torn) {
+    std::string note = path + ": " + std::to_string(records) + " records";
+    if (counts[TCRC_CNT_MISMATCH])
+      note += ", " + std::to_string(counts[TCRC_CNT_MISMATCH]) + " with a checksum mismatch (first in 32 KiB block " +
+              std::to_string(counts[TCRC_CNT_FIRST_BAD]) + ")";
+    if (torn) note += ", torn record at the end of the file";
+    report->log_notes.push_back(note);
+  }
+  return Status::OK();
+}
+
+}  // namespace
+
+Status VerifyTableFiles(tcrc_ctx* ctx, const std::vector<std::string>& files, uint32_t shard_index, uint32_t shard_count,
+                        DbVerifyReport* report, const SstVerifyOptions& options) {
+  if (shard_count == 0 || shard_index >= shard_count) return Status::InvalidArgument("bad shard index / count");
+  for (size_t i = 0; i < files.size(); ++i) {
+    if (i % shard_count != shard_index) continue;
+    SstVerifyStats st;
+    Status s = VerifySstFileChecksum(ctx, files[i], options, &st);
+    if (s.code() == Status::kNotSupported) {
+      ++report->table_files_declined;
+      continue;
+    }
+    ++report->table_files;
+    report->table_blocks += st.meta_blocks + st.index_blocks + st.data_blocks;
+    report->table_bytes_covered += st.bytes_covered;
+    if (!s.ok()) {
+      report->first_bad_file = files[i];
+      return s;
+    }
+  }
+  return Status::OK();
+}
+
+Status VerifyDbDirectory(tcrc_ctx* ctx, const std::string& dir, uint32_t shard_index, uint32_t shard_count,
+                         DbVerifyReport* report, const SstVerifyOptions& options) {
+  if (shard_count == 0 || shard_index >= shard_count) return Status::InvalidArgument("bad shard index / count");
+  DIR* d = opendir(dir.c_str());
+  if (!d) return Status::IOError("cannot list " + dir + ": " + strerror(errno));
+  std::vector<Named> tables, logs;
+  while (struct dirent* e = readdir(d)) {
+    const std::string name = e->d_name;
+    uint64_t num = 0;
+    if (NumberedName(name, ".sst", &num) || NumberedName(name, ".ldb", &num)) {
+      tables.push_back(Named{num, dir + "/" + name});
+    } else if (NumberedName(name, ".log", &num)) {
+      logs.push_back(Named{num, dir + "/" + name});
+    } else if (name.compare(0, 9, "MANIFEST-") == 0 && NumberedName(name.substr(9), "", &num)) {
+      logs.push_back(Named{num, dir + "/" + name});
+    }
+  }
+  closedir(d);
+  std::sort(tables.begin(), tables.end());
+  std::sort(logs.begin(), logs.end());
+  std::vector<std::string> files;
+  for (const Named& t : tables) files.push_back(t.path);
+  Status s = VerifyTableFiles(ctx, files, shard_index, shard_count, report, options);
+  if (!s.ok()) return s;
+  for (size_t i = 0; i < logs.size(); ++i) {
+    if (i % shard_count != shard_index) continue;
+    s = ScanLogFile(ctx, logs[i].path, report);
+    if (!s.ok()) {
+      report->first_bad_file = logs[i].path;
+      return s;
+    }
+  }
+  return Status::OK();
+}
+
+}  // namespace terarkdb_amd

@@ -9,6 +9,7 @@
 
 #include "../../include/tcrc_shim.h"
 #include "block_trailer.h"
+#include "db_verify.h"
 #include "file_checksum.h"
 #include "sst_verify.h"
 #include "wal_dump.h"
@@ -414,6 +415,21 @@ int tcrc_shim_footer_decode(const void* tail, size_t n, int* checksum, uint32_t*
   }
   if (message && message_cap) snprintf(message, message_cap, "%s", s.ToString().c_str());
   return s.ok() ? 0 : -1;
+}
+
+int tcrc_shim_verify_db(tcrc_ctx* ctx, const char* dir, uint32_t shard_index, uint32_t shard_count, uint64_t* report_out,
+                        char* message, size_t message_cap, char* bad_file, size_t bad_file_cap) {
+  DbVerifyReport rep;
+  Status s = VerifyDbDirectory(ctx, dir, shard_index, shard_count, &rep);
+  if (report_out) {
+    const uint64_t v[8] = {rep.table_files, rep.table_files_declined, rep.table_blocks, rep.table_bytes_covered,
+                           rep.log_files,   rep.log_bytes,            rep.log_records,  rep.log_bad_records};
+    memcpy(report_out, v, sizeof(v));
+  }
+  if (message && message_cap) snprintf(message, message_cap, "%s", s.ToString().c_str());
+  if (bad_file && bad_file_cap) snprintf(bad_file, bad_file_cap, "%s", rep.first_bad_file.c_str());
+  if (s.ok()) return 0;
+  return s.IsCorruption() ? 1 : -1;
 }
 
 int tcrc_shim_file_checksum(tcrc_ctx* ctx, const char* path, uint64_t size_limit, size_t buffer_size,

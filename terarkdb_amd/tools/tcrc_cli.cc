@@ -2,6 +2,9 @@
 //   tcrc crc32c [--block_size=N] [--bytes=N] [--device=D]      db_bench "crc32c" (tools/db_bench_tool.cc:3069-3088)
 //   tcrc verify FILE.sst...                                    sst_dump --command=verify (tools/sst_dump_tool.cc:656-665)
 //   tcrc dump_wal --walfile=F [--header] [--print_value]       ldb dump_wal (tools/ldb_cmd.cc:1967-2037)
+//   tcrc verify_db DIR [--shard=I/N]                           DBImpl::VerifyChecksum over the files of a
+//                                                              database directory (db/db_impl.cc:4657-4690), plus a
+//                                                              scan of its logs and MANIFEST files
 //   tcrc file_checksum FILE...                                 backup engine's CalculateChecksum
 //                                                              (utilities/backupable/backupable_db.cc:1414-1452)
 // All arithmetic runs on the GPU; without one every command fails at start-up.
@@ -14,6 +17,7 @@
 #include <vector>
 
 #include "../../include/tcrc.h"
+#include "../host/db_verify.h"
 #include "../host/file_checksum.h"
 #include "../host/sst_verify.h"
 #include "../host/wal_dump.h"
@@ -152,6 +156,42 @@ int CmdDumpWal(tcrc_ctx* ctx, int argc, char** argv) {
   return 0;
 }
 
+int CmdVerifyDb(tcrc_ctx* ctx, int argc, char** argv) {
+  std::string dir, v;
+  uint32_t shard = 0, shards = 1;
+  for (int i = 0; i < argc; ++i) {
+    if (Flag(argv[i], "--shard", &v)) {
+      if (sscanf(v.c_str(), "%u/%u", &shard, &shards) != 2) {
+        fprintf(stderr, "--shard=I/N\n");
+        return 2;
+      }
+    } else if (argv[i][0] != '-') {
+      dir = argv[i];
+    }
+  }
+  if (dir.empty()) {
+    fprintf(stderr, "verify_db needs a directory\n");
+    return 2;
+  }
+  DbVerifyReport rep;
+  const double t0 = NowMicros();
+  Status s = VerifyDbDirectory(ctx, dir, shard, shards, &rep);
+  const double t1 = NowMicros();
+  printf("table files: %llu verified (%llu blocks, %llu bytes covered), %llu declined\n",
+         (unsigned long long)rep.table_files, (unsigned long long)rep.table_blocks,
+         (unsigned long long)rep.table_bytes_covered, (unsigned long long)rep.table_files_declined);
+  printf("log files: %llu (%llu bytes, %llu records, %llu with a checksum mismatch)\n", (unsigned long long)rep.log_files,
+         (unsigned long long)rep.log_bytes, (unsigned long long)rep.log_records, (unsigned long long)rep.log_bad_records);
+  for (const std::string& n : rep.log_notes) printf("  %s\n", n.c_str());
+  fprintf(stderr, "%.1f MB/s\n", (rep.table_bytes_covered + rep.log_bytes) / 1048576.0 / ((t1 - t0) * 1e-6));
+  if (!s.ok()) {
+    fprintf(stderr, "%s is corrupted: %s\n", rep.first_bad_file.c_str(), s.ToString().c_str());
+    return 1;
+  }
+  printf("OK\n");
+  return rep.log_bad_records ? 1 : 0;
+}
+
 int CmdFileChecksum(tcrc_ctx* ctx, int argc, char** argv) {
   int bad = 0;
   for (int i = 0; i < argc; ++i) {
@@ -178,6 +218,7 @@ void Usage() {
           "  crc32c [--block_size=N] [--bytes=N]\n"
           "  verify FILE.sst ...\n"
           "  dump_wal --walfile=FILE [--header] [--print_value]\n"
+          "  verify_db DIR [--shard=I/N]\n"
           "  file_checksum FILE ...\n");
 }
 
@@ -195,7 +236,7 @@ int main(int argc, char** argv) {
     return 2;
   }
   const std::string cmd = argv[at++];
-  if (cmd != "crc32c" && cmd != "verify" && cmd != "dump_wal" && cmd != "file_checksum") {
+  if (cmd != "crc32c" && cmd != "verify" && cmd != "dump_wal" && cmd != "file_checksum" && cmd != "verify_db") {
     Usage();
     return 2;
   }
@@ -208,6 +249,7 @@ int main(int argc, char** argv) {
   if (cmd == "crc32c") rc = CmdCrc32c(ctx, argc - at, argv + at);
   else if (cmd == "verify") rc = CmdVerify(ctx, argc - at, argv + at);
   else if (cmd == "dump_wal") rc = CmdDumpWal(ctx, argc - at, argv + at);
+  else if (cmd == "verify_db") rc = CmdVerifyDb(ctx, argc - at, argv + at);
   else rc = CmdFileChecksum(ctx, argc - at, argv + at);
   tcrc_shutdown(ctx);
   return rc;

@@ -54,3 +54,74 @@ def test_dump_wal(tmp_path):
     rc, out, err = run("dump_wal", "--walfile=" + path, "--header")
     assert rc == 0 and err == ""
     assert out == W.HEADER + "\n" + "".join(b.row(off, False) for b, (_, off) in zip(batches, recs))
+
+
+def _make_db_dir(tmp_path):
+    """A directory shaped like a database: table files, write-ahead logs, a MANIFEST, other files."""
+    import shutil
+    d = tmp_path / "db"
+    d.mkdir()
+    lays = [S.build_table(str(d / ("%06d.sst" % (10 + i))), n_data=30 + 5 * i, seed=60 + i,
+                          index="two_level" if i % 2 else "binary") for i in range(5)]
+    zipt = S.build_table(str(d / "000099.sst"), n_data=2)
+    raw = bytearray(open(zipt.path, "rb").read())
+    raw[-8:] = (0x1122334455667788).to_bytes(8, "little")  # another table format: declined, not corrupt
+    open(zipt.path, "wb").write(raw)
+    imgs = {}
+    for num, recycle in ((3, False), (4, True)):
+        img = O.build_wal_image(recycle, log_number=num, n_random=80, seed=num)
+        open(str(d / ("%06d.log" % num)), "wb").write(img)
+        imgs[num] = img
+    here = os.path.dirname(os.path.abspath(__file__))
+    shutil.copy(os.path.join(here, "golden", "reference_MANIFEST-CORRECT.bin"), str(d / "MANIFEST-000005"))
+    for name in ("CURRENT", "LOCK", "OPTIONS-000007", "LOG"):
+        open(str(d / name), "w").write("x\n")
+    return d, lays, imgs
+
+
+def test_verify_db_directory(tmp_path):
+    import ctypes as C
+    import gpu_util as G
+    import terarkdb_amd.capi as capi
+    d, lays, imgs = _make_db_dir(tmp_path)
+    eng = G.engine()
+
+    def verify(shard=0, shards=1):
+        rep = (C.c_uint64 * 8)()
+        msg, bad = C.create_string_buffer(1024), C.create_string_buffer(1024)
+        rc = capi.lib.tcrc_shim_verify_db(eng.ctx, str(d).encode(), shard, shards, rep, msg, 1024, bad, 1024)
+        return rc, [int(x) for x in rep], msg.value.decode(), bad.value.decode()
+
+    n_log_recs = sum(int(O.wal_scan_blocks(imgs[k], k)[:, 0].sum()) for k in imgs)
+    manifest = open(str(d / "MANIFEST-000005"), "rb").read()
+    n_manifest = int(O.wal_scan_blocks(manifest, 5)[:, 0].sum())
+    rc, rep, msg, bad = verify()
+    assert (rc, msg, bad) == (0, "OK", "")
+    assert rep[0] == 5 and rep[1] == 1
+    assert rep[2] == sum(l.n_meta + l.n_index + l.n_data for l in lays)
+    assert rep[3] == sum(sz + 1 for l in lays for _, _, sz in l.order)
+    assert rep[4] == 3 and rep[5] == sum(len(v) for v in imgs.values()) + len(manifest)
+    assert rep[6] == n_log_recs + n_manifest and rep[7] == 0
+    # two shards cover the directory between them
+    r0, r1 = verify(0, 2), verify(1, 2)
+    assert r0[0] == 0 and r1[0] == 0
+    assert [a + b for a, b in zip(r0[1], r1[1])] == rep
+    # a corrupt table stops the run with the reference's status; a bad log record is counted
+    off, size = lays[2].handle("data7")
+    S.flip(lays[2].path, off + 3, 1)
+    with open(str(d / "000003.log"), "r+b") as f:
+        f.seek(40000)
+        b = f.read(1)[0]
+        f.seek(40000)
+        f.write(bytes([b ^ 0x20]))
+    rc, rep2, msg, bad = verify()
+    assert rc == 1 and bad == lays[2].path and msg == S.expected_status(lays[2])
+    assert rep2[0] == 3 and rep2[4] == 0  # the run ended at the third table file
+    os.remove(lays[2].path)
+    rc, rep3, msg, bad = verify()
+    assert (rc, msg) == (0, "OK") and rep3[0] == 4 and rep3[7] == 1
+    eng.close()
+    # the same through the command line
+    rc, out, err = run("verify_db", str(d))
+    assert rc == 1 and "log files: 3" in out and "1 with a checksum mismatch" in out and "000003.log" in out
+    assert "table files: 4 verified" in out and "1 declined" in out and out.rstrip().endswith("OK")
