@@ -252,3 +252,36 @@ def test_batch_entry_points_can_be_captured_in_a_graph():
         else:
             assert int(c[capi.CNT_MISMATCH]) == 1 and int(c[capi.CNT_FIRST_BAD]) == 5
     eng.close()
+
+
+@pytest.mark.parametrize("n", [37, 5000, 20000])  # the engine picks 64, 16 and 8 lanes per buffer for these
+def test_randomised_descriptor_batches_with_engine_chosen_geometry(n):
+    import gpu_util as G
+    import terarkdb_amd.capi as capi
+    eng = G.engine()
+    host = O.splitmix(3 << 20, 1234 + n)
+    dev = G.to_dev(host)
+    for seed in range(6):
+        rng = np.random.default_rng(1000 * n + seed)
+        kind = rng.integers(0, 5, n)
+        lens = np.where(kind == 0, rng.integers(0, 40, n),                     # tiny, including empty
+               np.where(kind == 1, 16 * rng.integers(0, 64, n),               # multiples of a column
+               np.where(kind == 2, 128 * rng.integers(1, 40, n),              # multiples of a row
+               np.where(kind == 3, rng.integers(1, 70000 if n < 100 else 6000, n),
+                        rng.integers(1000, 1100, n))))).astype(np.uint32)
+        offs = rng.integers(0, host.size - 70001, n).astype(np.uint64)
+        if seed % 2:
+            offs &= ~np.uint64(127)                                            # line-aligned starts
+        inits = rng.integers(0, 2**32, n).astype(np.uint32)
+        sfx = rng.integers(0, 256, n).astype(np.uint8) if seed % 3 == 0 else None
+        masked = bool(seed & 1)
+        desc = capi.make_desc_tensor(offs, lens, inits, "cuda")
+        out = torch.zeros(n, dtype=torch.int32, device="cuda")
+        eng.batch_stamp(dev, desc, n, out, suffix=None if sfx is None else G.to_dev(sfx),
+                        flags=capi.F_MASK if masked else 0)
+        torch.cuda.synchronize()
+        want = O.batch_extend(host, offs, lens, inits, sfx, masked)
+        got = out.cpu().numpy().view(np.uint32)
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, (n, seed, bad[:5], lens[bad[:5]], offs[bad[:5]] % 1024)
+    eng.close()
