@@ -648,6 +648,7 @@ int tcrc_shutdown(tcrc_ctx* ctx) {
   if (ctx->host_stream) (void)hipStreamDestroy(ctx->host_stream);
   for (auto& e : ctx->pin_free) (void)hipHostFree(e.first);
   if (ctx->stage_ring) (void)hipHostFree(ctx->stage_ring);
+  if (ctx->zc) (void)hipHostFree(ctx->zc);
   for (hipEvent_t ev : ctx->stage_done)
     if (ev) (void)hipEventDestroy(ev);
   delete ctx;

@@ -23,14 +23,31 @@ int host_begin(tcrc_ctx* ctx) {
   return TCRC_OK;
 }
 
-// True when p is host memory the DMA engines can read directly (allocated or registered pinned).
-bool is_pinned(const void* p) {
+// Layout of the zero-copy block
+constexpr size_t kZcDescOff = tcrc_ctx::kZcData;
+constexpr size_t kZcSuffixOff = kZcDescOff + tcrc_ctx::kZcMaxItems * sizeof(tcrc_desc);
+constexpr size_t kZcOutOff = kZcSuffixOff + tcrc_ctx::kZcMaxItems;
+constexpr size_t kZcBytes = kZcOutOff + tcrc_ctx::kZcMaxItems * 4;
+// Above this many input bytes a copy to HBM pays for itself (the kernel reads host memory at link speed).
+constexpr size_t kZcMaxInput = (size_t)1 << 20;
+
+int zc_begin(tcrc_ctx* ctx) {
+  if (!ctx->zc)
+    HIP_TRY(hipHostMalloc((void**)&ctx->zc, kZcBytes, hipHostMallocMapped | hipHostMallocCoherent));
+  return TCRC_OK;
+}
+
+// True when p is host memory the DMA engines can read directly (allocated or registered pinned);
+// *dev, if given, receives the address a kernel uses for it.
+bool is_pinned(const void* p, const void** dev = nullptr) {
   hipPointerAttribute_t a;
   if (hipPointerGetAttributes(&a, p) != hipSuccess) {
     (void)hipGetLastError();  // ordinary pageable memory is "invalid value" to the runtime
     return false;
   }
-  return a.type == hipMemoryTypeHost;
+  if (a.type != hipMemoryTypeHost || !a.devicePointer) return false;
+  if (dev) *dev = a.devicePointer;
+  return true;
 }
 
 // Copies pageable host memory to the device through a ring of pinned slots: several host threads
@@ -166,6 +183,25 @@ int tcrc_host_batch_stamp(tcrc_ctx* ctx, const void* h_base, uint64_t base_bytes
   HostCallTimer timer(ctx);
   std::lock_guard<std::mutex> lock(ctx->host_mu);
   if (int rc = host_begin(ctx)) return rc;
+  if (n <= tcrc_ctx::kZcMaxItems && base_bytes <= kZcMaxInput && (base_bytes <= tcrc_ctx::kZcData || is_pinned(h_base))) {
+    // Small batch: no copies.  The kernel reads the bytes where they are (pinned memory) or from the bounce
+    // area, takes its descriptors from the zero-copy block and writes the results there.
+    if (int rc = zc_begin(ctx)) return rc;
+    const void* base = nullptr;
+    if (!is_pinned(h_base, &base)) {
+      memcpy(ctx->zc, h_base, base_bytes);
+      base = ctx->zc;
+    }
+    memcpy(ctx->zc + kZcDescOff, h_desc, n * sizeof(tcrc_desc));
+    if (h_suffix) memcpy(ctx->zc + kZcSuffixOff, h_suffix, n);
+    if (int rc = tcrc_dev_batch_stamp(ctx, base, (const tcrc_desc*)(ctx->zc + kZcDescOff), n,
+                                      h_suffix ? (const uint8_t*)(ctx->zc + kZcSuffixOff) : nullptr, flags,
+                                      (uint32_t*)(ctx->zc + kZcOutOff), ctx->host_stream))
+      return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->host_stream));
+    memcpy(h_out, ctx->zc + kZcOutOff, n * 4);
+    return TCRC_OK;
+  }
   if (int rc = upload(ctx, &ctx->host_data, h_base, base_bytes)) return rc;
   if (int rc = upload(ctx, &ctx->host_desc, h_desc, n * sizeof(tcrc_desc))) return rc;
   if (h_suffix)
@@ -321,13 +357,20 @@ int tcrc_extend(tcrc_ctx* ctx, uint32_t init, const void* h_data, size_t n, uint
   if (int rc = scratch_reserve(ctx, &ctx->host_out, 64)) return rc;
   uint32_t crc = init;
   if (n <= (16u << 10)) {
-    // short input: one wave walks it in a single launch (the segment machinery costs more than it saves)
-    if (int rc = upload(ctx, &ctx->host_data, h_data, n)) return rc;
-    if (int rc = tcrc_dev_blocks_stamp(ctx, ctx->host_data.p, 1, (uint32_t)n, n, init, -1, nullptr, 0,
-                                       (uint32_t*)ctx->host_out.p, ctx->host_stream))
+    // short input: one wave walks it in a single launch, reading it from the zero-copy block (or where it
+    // lies, if that is pinned memory) and leaving the result there - no copy commands at all
+    if (int rc = zc_begin(ctx)) return rc;
+    const void* base = nullptr;
+    if (!is_pinned(h_data, &base)) {
+      memcpy(ctx->zc, h_data, n);
+      base = ctx->zc;
+    }
+    ctx->st_host_bytes_in.fetch_add(n, std::memory_order_relaxed);
+    if (int rc = tcrc_dev_blocks_stamp(ctx, base, 1, (uint32_t)n, n, init, -1, nullptr, 0,
+                                       (uint32_t*)(ctx->zc + kZcOutOff), ctx->host_stream))
       return rc;
-    HIP_TRY(hipMemcpyAsync(&crc, ctx->host_out.p, 4, hipMemcpyDeviceToHost, ctx->host_stream));
     HIP_TRY(hipStreamSynchronize(ctx->host_stream));
+    memcpy(&crc, ctx->zc + kZcOutOff, 4);
     *out = crc;
     return TCRC_OK;
   }

@@ -92,6 +92,11 @@ struct tcrc_ctx {
   tcrc_scratch long_in, long_desc, long_owner, long_after, long_pow, long_acc;
   uint32_t long_pow_seg = 0;      // segment length the cached power table was built for
   uint32_t long_pow_count = 0;    // entries in it
+  // Small host calls skip the copies: the kernel reads descriptors (and short inputs) from, and writes its
+  // results to, this block of pinned host memory that the GPU addresses directly.  Guarded by host_mu.
+  static constexpr size_t kZcData = (size_t)64 << 10;     // bounce area for short pageable inputs
+  static constexpr size_t kZcMaxItems = 4096;
+  char* zc = nullptr;                                      // [data | descriptors | suffix bytes | outputs]
   // Staging ring for uploads from pageable memory (tcrc_host.hip), guarded by host_mu
   static constexpr int kStageSlots = 12;
   static constexpr size_t kStageSlotBytes = (size_t)4 << 20;
