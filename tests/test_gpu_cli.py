@@ -125,3 +125,29 @@ def test_verify_db_directory(tmp_path):
     rc, out, err = run("verify_db", str(d))
     assert rc == 1 and "log files: 3" in out and "1 with a checksum mismatch" in out and "000003.log" in out
     assert "table files: 4 verified" in out and "1 declined" in out and out.rstrip().endswith("OK")
+
+
+def test_python_file_helpers(tmp_path):
+    import gpu_util as G
+    import terarkdb_amd.capi as capi
+    import terarkdb_amd.files as F
+    d, lays, imgs = _make_db_dir(tmp_path)
+    eng = G.engine()
+    r = F.verify_table_file(eng, lays[1].path)
+    assert r.ok and r.status == "OK" and r.data_blocks == lays[1].n_data and r.mismatches == 0
+    assert F.verify_table_file(eng, str(d / "000099.sst")).declined
+    S.flip(lays[1].path, lays[1].handle("index")[0] + 2, 0)
+    r = F.verify_table_file(eng, lays[1].path)
+    assert not r.ok and not r.declined and r.status == S.expected_status(lays[1])
+    db = F.verify_db_directory(eng, str(d))
+    assert not db.ok and db.bad_file == lays[1].path and db.status == r.status and db.table_files == 2
+    rows, errs = F.dump_wal(eng, str(d / "MANIFEST-000005"))
+    assert errs.count("log record too small") >= 0 and isinstance(rows, str)
+    raw = np.fromfile(lays[0].path, dtype=np.uint8)
+    assert F.file_checksum(eng, lays[0].path) == (O.value(raw), raw.size)
+    assert F.file_checksum(eng, lays[0].path, size_limit=1000) == (O.value(raw[:1000]), 1000)
+    with pytest.raises(capi.TcrcError):
+        F.file_checksum(eng, str(d / "missing"))
+    with pytest.raises(capi.TcrcError):
+        F.verify_table_file(eng, str(d / "missing.sst"))
+    eng.close()
