@@ -151,3 +151,23 @@ def test_python_file_helpers(tmp_path):
     with pytest.raises(capi.TcrcError):
         F.verify_table_file(eng, str(d / "missing.sst"))
     eng.close()
+
+
+def test_verify_db_module_under_torchrun(tmp_path):
+    """The multi-GPU directory verification with one rank (the RCCL path; more ranks need more GPUs)."""
+    import socket
+    import sys
+    d, lays, imgs = _make_db_dir(tmp_path)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), "-m", "terarkdb_amd.verify_db", str(d)]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd=ROOT)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "table files: 5 verified" in p.stdout and "1 declined" in p.stdout and p.stdout.rstrip().endswith("OK")
+    S.flip(lays[3].path, lays[3].handle("data2")[0] + 1, 6)
+    p = subprocess.run([sys.executable, "-m", "terarkdb_amd.verify_db", str(d)], capture_output=True, text=True,
+                       timeout=240, cwd=ROOT)
+    assert p.returncode == 1 and ("%s is corrupted: %s" % (lays[3].path, S.expected_status(lays[3]))) in p.stdout
