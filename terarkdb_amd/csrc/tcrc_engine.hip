@@ -516,7 +516,7 @@ int fail(int code, const std::string& msg) {
 
 int scratch_reserve(tcrc_ctx* ctx, tcrc_scratch* s, size_t bytes) {
   if (s->bytes >= bytes) return TCRC_OK;
-  HIP_TRY(hipSetDevice(ctx->device));
+  TCRC_DEVICE_SCOPE(ctx);
   if (s->p) {
     HIP_TRY(hipDeviceSynchronize());  // earlier work may still use the old block
     (void)hipFree(s->p);
@@ -539,7 +539,7 @@ int run_batch(tcrc_ctx* ctx, BatchParams p, void* stream) {
   if (!ctx) return fail(TCRC_ERR_INVALID, "null context");
   if (p.n == 0) return TCRC_OK;
   if (!p.base) return fail(TCRC_ERR_INVALID, "null base pointer");
-  HIP_TRY(hipSetDevice(ctx->device));
+  TCRC_DEVICE_SCOPE(ctx);
   hipStream_t s = (hipStream_t)stream;
   int g = ctx->forced_g;  // set for experiments only
   if (g == 0 && p.lanes) g = p.lanes;  // the caller knows the shape of its spans (log scans)
@@ -587,7 +587,8 @@ int tcrc_init(int device, tcrc_ctx** out) {
     return fail(TCRC_ERR_NO_DEVICE, std::string("no HIP device available (") + hipGetErrorString(ce) +
                                         "): the tcrc engine has no CPU fallback");
   if (device < 0 || device >= count) return fail(TCRC_ERR_INVALID, "device index out of range");
-  HIP_TRY(hipSetDevice(device));
+  tcrc_internal::DeviceScope device_scope(device);
+  HIP_TRY(device_scope.err);
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, device));
   tcrc_ctx* ctx = new tcrc_ctx();
@@ -634,7 +635,7 @@ int tcrc_debug_tables(int lanes, uint32_t* main_out, uint32_t* aux_out, size_t a
 
 int tcrc_shutdown(tcrc_ctx* ctx) {
   if (!ctx) return TCRC_OK;
-  (void)hipSetDevice(ctx->device);
+  tcrc_internal::DeviceScope device_scope(ctx->device);
   for (int gi = 0; gi < kGeoCount; ++gi) {
     if (ctx->d_tab_main[gi]) (void)hipFree(ctx->d_tab_main[gi]);
     if (ctx->d_tab_aux[gi]) (void)hipFree(ctx->d_tab_aux[gi]);
@@ -682,7 +683,7 @@ const char* tcrc_describe(tcrc_ctx* ctx) { return ctx ? ctx->description.c_str()
 
 int tcrc_dev_counts_reset(tcrc_ctx* ctx, uint64_t* d_counts, void* stream) {
   if (!ctx || !d_counts) return fail(TCRC_ERR_INVALID, "null argument");
-  HIP_TRY(hipSetDevice(ctx->device));
+  TCRC_DEVICE_SCOPE(ctx);
   hipLaunchKernelGGL(k_counts_reset, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)d_counts);
   HIP_TRY(hipGetLastError());
   return TCRC_OK;
@@ -693,7 +694,7 @@ int tcrc_dev_probe_read(tcrc_ctx* ctx, const void* d_base, uint64_t nbytes, uint
   if (!ctx || !d_base || !d_scratch) return fail(TCRC_ERR_INVALID, "null argument");
   if (((uintptr_t)d_base & 15u) != 0) return fail(TCRC_ERR_INVALID, "probe needs a 16-byte aligned base");
   if (wgs_per_cu == 0 || wgs_per_cu > 2) return fail(TCRC_ERR_INVALID, "wgs_per_cu must be 1 or 2");
-  HIP_TRY(hipSetDevice(ctx->device));
+  TCRC_DEVICE_SCOPE(ctx);
   if (ctx->nontemporal)
     hipLaunchKernelGGL(k_probe_read<true>, dim3((unsigned)ctx->cus * wgs_per_cu), dim3(kThreads), 0,
                        (hipStream_t)stream, (const uint8_t*)d_base, nbytes / 16, d_scratch);

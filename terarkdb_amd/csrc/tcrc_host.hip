@@ -17,8 +17,7 @@ using namespace tcrc_internal;
 
 namespace {
 
-int host_begin(tcrc_ctx* ctx) {
-  HIP_TRY(hipSetDevice(ctx->device));
+int host_begin(tcrc_ctx* ctx) {  // the caller has made the context's GPU current
   if (!ctx->host_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->host_stream, hipStreamNonBlocking));
   return TCRC_OK;
 }
@@ -139,7 +138,8 @@ void* tcrc_host_alloc(tcrc_ctx* ctx, size_t bytes) {
       return e.first;
     }
   }
-  if (hipSetDevice(ctx->device) != hipSuccess) return nullptr;
+  tcrc_internal::DeviceScope scope(ctx->device);
+  if (scope.err != hipSuccess) return nullptr;
   void* p = nullptr;
   if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
   std::lock_guard<std::mutex> lock(ctx->pin_mu);
@@ -182,6 +182,7 @@ int tcrc_host_batch_stamp(tcrc_ctx* ctx, const void* h_base, uint64_t base_bytes
     if (h_desc[i].offset + h_desc[i].len > base_bytes) return fail(TCRC_ERR_INVALID, "descriptor outside the buffer");
   HostCallTimer timer(ctx);
   std::lock_guard<std::mutex> lock(ctx->host_mu);
+  TCRC_DEVICE_SCOPE(ctx);
   if (int rc = host_begin(ctx)) return rc;
   if (n <= tcrc_ctx::kZcMaxItems && base_bytes <= kZcMaxInput && (base_bytes <= tcrc_ctx::kZcData || is_pinned(h_base))) {
     // Small batch: no copies.  The kernel reads the bytes where they are (pinned memory) or from the bounce
@@ -224,6 +225,7 @@ int tcrc_host_blocks_stamp(tcrc_ctx* ctx, const void* h_base, uint64_t n_blocks,
   if (flags & TCRC_F_STORE_AFTER) return fail(TCRC_ERR_INVALID, "host entry points return the values: nothing to store into");
   HostCallTimer timer(ctx);
   std::lock_guard<std::mutex> lock(ctx->host_mu);
+  TCRC_DEVICE_SCOPE(ctx);
   if (int rc = host_begin(ctx)) return rc;
   const uint64_t bytes = (n_blocks - 1) * stride + block_len;
   if (int rc = upload(ctx, &ctx->host_data, h_base, bytes)) return rc;
@@ -255,6 +257,7 @@ int tcrc_host_batch_verify(tcrc_ctx* ctx, const void* h_base, uint64_t base_byte
   }
   HostCallTimer timer(ctx);
   std::lock_guard<std::mutex> lock(ctx->host_mu);
+  TCRC_DEVICE_SCOPE(ctx);
   if (int rc = host_begin(ctx)) return rc;
   if (int rc = upload(ctx, &ctx->host_data, h_base, base_bytes)) return rc;
   if (int rc = upload(ctx, &ctx->host_desc, h_desc, n * sizeof(tcrc_desc))) return rc;
@@ -292,6 +295,7 @@ int tcrc_host_wal_verify(tcrc_ctx* ctx, const void* h_img, uint64_t size, uint64
   if (!h_img || !h_blocks) return fail(TCRC_ERR_INVALID, "null argument");
   HostCallTimer timer(ctx);
   std::lock_guard<std::mutex> lock(ctx->host_mu);
+  TCRC_DEVICE_SCOPE(ctx);
   if (int rc = host_begin(ctx)) return rc;
   const uint64_t nblocks = (size + 32767) / 32768;
   if (int rc = upload(ctx, &ctx->host_data, h_img, size)) return rc;
@@ -316,6 +320,7 @@ int tcrc_host_wal_list(tcrc_ctx* ctx, const void* h_img, uint64_t size, uint64_t
   if (!h_img || (capacity && !h_records)) return fail(TCRC_ERR_INVALID, "null argument");
   HostCallTimer timer(ctx);
   std::lock_guard<std::mutex> lock(ctx->host_mu);
+  TCRC_DEVICE_SCOPE(ctx);
   if (int rc = host_begin(ctx)) return rc;
   const uint64_t nblocks = (size + 32767) / 32768;
   if (int rc = upload(ctx, &ctx->host_data, h_img, size)) return rc;
@@ -350,6 +355,7 @@ int tcrc_extend(tcrc_ctx* ctx, uint32_t init, const void* h_data, size_t n, uint
   if (!h_data) return fail(TCRC_ERR_INVALID, "null argument");
   HostCallTimer timer(ctx);
   std::lock_guard<std::mutex> lock(ctx->host_mu);
+  TCRC_DEVICE_SCOPE(ctx);
   if (int rc = host_begin(ctx)) return rc;
   // Pieces of up to 256 MiB, chained through init like the callers that feed a file through
   // Extend buffer by buffer (utilities/backupable/backupable_db.cc:1434-1449).

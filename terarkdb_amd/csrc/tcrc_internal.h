@@ -56,6 +56,28 @@ void build_tables(int G, std::vector<uint32_t>* main_tab, std::vector<uint32_t>*
 // Launches the batch CRC kernel for the geometry the context prefers.
 int run_batch(tcrc_ctx* ctx, BatchParams p, void* stream);
 
+// Makes the context's GPU the calling thread's current device for the rest of the scope and puts the
+// caller's device back afterwards (a multi-GPU host must not find its current device changed by a call).
+struct DeviceScope {
+  int prev = -1;
+  bool changed = false;
+  hipError_t err = hipSuccess;
+  explicit DeviceScope(int device) {
+    err = hipGetDevice(&prev);
+    if (err == hipSuccess && prev != device) {
+      err = hipSetDevice(device);
+      changed = err == hipSuccess;
+    }
+  }
+  ~DeviceScope() {
+    if (changed) (void)hipSetDevice(prev);
+  }
+};
+#define TCRC_DEVICE_SCOPE(ctx_)                                                                        \
+  tcrc_internal::DeviceScope device_scope_((ctx_)->device);                                            \
+  if (device_scope_.err != hipSuccess)                                                                 \
+  return tcrc_internal::fail(TCRC_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(device_scope_.err))
+
 #define HIP_TRY(expr)                                                                                  \
   do {                                                                                                 \
     hipError_t e_ = (expr);                                                                            \

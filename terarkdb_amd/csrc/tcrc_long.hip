@@ -89,7 +89,7 @@ extern "C" int tcrc_dev_extend_long(tcrc_ctx* ctx, const void* d_base, const tcr
   if (n == 0) return TCRC_OK;
   if (!d_base || !h_desc || !d_out) return fail(TCRC_ERR_INVALID, "null argument");
   if (n > (1u << 24)) return fail(TCRC_ERR_TOO_LARGE, "too many buffers in one long-buffer call");
-  HIP_TRY(hipSetDevice(ctx->device));
+  TCRC_DEVICE_SCOPE(ctx);
   hipStream_t s = (hipStream_t)stream;
   uint64_t total = 0, longest = 0;
   for (uint64_t i = 0; i < n; ++i) {

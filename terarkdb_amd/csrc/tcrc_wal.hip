@@ -363,7 +363,7 @@ extern "C" int tcrc_dev_wal_frame(tcrc_ctx* ctx, const void* d_src, const tcrc_d
   const uint64_t total = plan_frames(h_recs, n, recycle != 0, block_offset, &frags, &bo, &phys);
   if (total > dst_capacity) return fail(TCRC_ERR_INVALID, "dst_capacity is smaller than the framed size");
   if (frags.size() >= (1ull << 32)) return fail(TCRC_ERR_TOO_LARGE, "too many physical records in one call");
-  HIP_TRY(hipSetDevice(ctx->device));
+  TCRC_DEVICE_SCOPE(ctx);
   std::lock_guard<std::mutex> lock(ctx->wal_mu);
   hipStream_t s = (hipStream_t)stream;
   const size_t frag_bytes = frags.size() * sizeof(Frag);
@@ -401,7 +401,7 @@ extern "C" int tcrc_dev_wal_list(tcrc_ctx* ctx, const void* d_img, uint64_t size
   if (h_count) *h_count = 0;
   if (size == 0) return TCRC_OK;
   if (!d_img || !d_blocks || (capacity && !d_records)) return fail(TCRC_ERR_INVALID, "null argument");
-  HIP_TRY(hipSetDevice(ctx->device));
+  TCRC_DEVICE_SCOPE(ctx);
   std::lock_guard<std::mutex> lock(ctx->wal_mu);
   hipStream_t s = (hipStream_t)stream;
   const uint64_t nblocks = (size + kLogBlock - 1) / kLogBlock;
@@ -445,7 +445,7 @@ extern "C" int tcrc_dev_wal_verify(tcrc_ctx* ctx, const void* d_img, uint64_t si
   if (h_records) *h_records = 0;
   if (size == 0) return TCRC_OK;
   if (!d_img || !d_blocks || !d_counts) return fail(TCRC_ERR_INVALID, "null argument");
-  HIP_TRY(hipSetDevice(ctx->device));
+  TCRC_DEVICE_SCOPE(ctx);
   std::lock_guard<std::mutex> lock(ctx->wal_mu);  // the descriptor scratch belongs to one scan at a time
   ctx->st_log_images.fetch_add(1, std::memory_order_relaxed);
   ctx->st_log_bytes.fetch_add(size, std::memory_order_relaxed);
