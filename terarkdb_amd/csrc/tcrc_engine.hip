@@ -129,16 +129,16 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p) {
     const bool valid = buf < n;
     uint64_t off = 0;
     uint32_t len = 0, init = 0, item_index = 0;
-    const tcrc_desc d = d_next;
+    const tcrc_desc dsc = d_next;
     if (p.desc) {
       const uint64_t nb = (round + nwaves) * GPW + grp;
       if (round + nwaves < nrounds && nb < n) d_next = p.desc[nb];
     }
     if (valid) {
       if (p.desc) {
-        off = d.offset;
-        len = d.len;
-        init = d.init;
+        off = dsc.offset;
+        len = dsc.len;
+        init = dsc.init;
         if (wal_items) {
           item_index = init;  // record index inside its 32 KiB block
           init = 0;
@@ -323,9 +323,9 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p) {
     // Lanes -> lane G-1: at step d lanes [G-2d, G-d) hand Z_{16d}(u) to [G-d, G).
 #pragma unroll
     for (int st = LOG2G; st >= 1; --st) {
-      const int d = 1 << (st - 1);
+      const int dist = 1 << (st - 1);
       const uint32_t t = fold_aux(aux + st * 1024, u);
-      u ^= __shfl_up(t, d, G);
+      u ^= __shfl_up(t, dist, G);
     }
 
     // The last dword still owes its own four bytes; then the trailing zeros are taken back out:
@@ -352,25 +352,25 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p) {
     uint32_t seg_owner = 0, seg_value = 0;
     bool seg_have = false;
     if (valid && j == G - 1) {
-      uint32_t r;
+      uint32_t reg;
       if (live) {
-        r = rfin;
+        reg = rfin;
       } else {
-        r = r0;
+        reg = r0;
         const uint32_t* T0 = aux + 768;  // one-byte step table
-        for (uint32_t k = 0; k < len; ++k) r = T0[(r ^ ptr[k]) & 0xffu] ^ (r >> 8);
+        for (uint32_t k = 0; k < len; ++k) reg = T0[(reg ^ ptr[k]) & 0xffu] ^ (reg >> 8);
       }
       int sfx = p.uniform_suffix;
       if (p.suffix) sfx = p.suffix[buf];
-      if (sfx >= 0) r = aux[768u + ((r ^ (uint32_t)sfx) & 0xffu)] ^ (r >> 8);
-      const uint32_t crc = ~r;
+      if (sfx >= 0) reg = aux[768u + ((reg ^ (uint32_t)sfx) & 0xffu)] ^ (reg >> 8);
+      const uint32_t crc = ~reg;
       const uint32_t masked = ((crc >> 15) | (crc << 17)) + kMaskDelta;
       if (segments) {
-        // r is the remainder of this segment alone; q whole segments follow it in its buffer, so it
+        // reg is the remainder of this segment alone; q whole segments follow it in its buffer, so it
         // enters the buffer's remainder advanced through q * segment_len bytes.  The final inversion
         // rides on the last segment (q == 0).
         const uint32_t q = p.seg_after[buf];
-        const uint32_t prod = gf2_mulmod_dev(r, p.seg_pow[q]);
+        const uint32_t prod = gf2_mulmod_dev(reg, p.seg_pow[q]);
         seg_owner = p.seg_owner[buf];
         seg_value = q == 0 ? ~prod : prod;
         seg_have = true;
