@@ -1,0 +1,321 @@
+// Robustness driver for the host-side parsers, built with AddressSanitizer and UBSan (host code only,
+// no GPU): log reader, block cursor, footer decoder, write-batch printer and the table-file verification
+// driver are fed mutated and random inputs.  The checksum seams are served by the CPU oracle (test
+// infrastructure) or by a checker that accepts everything, so that parsing continues into damaged
+// structure a real checksum would have stopped.  Exit status 0 = no crash, no sanitizer report, all
+// invariants held.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <memory>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "../../terarkdb_amd/host/files.h"
+#include "../../terarkdb_amd/host/sst_verify.h"
+#include "../../terarkdb_amd/host/wal_dump.h"
+#include "../../terarkdb_amd/host/wal_reader.h"
+#include "../../terarkdb_amd/host/wal_writer.h"
+
+extern "C" {
+// the CPU oracle (oracle/*.c), linked in as the checker
+uint32_t oracle_crc32c_extend(uint32_t init, const void* data, size_t n);
+uint32_t oracle_crc32c_mask(uint32_t crc);
+void oracle_wal_scan_blocks(const uint8_t* img, size_t n, uint64_t log_number, uint32_t* out4);
+
+// The engine's C ABI is not linked into this driver: the device-backed classes are never instantiated
+// here, these definitions only satisfy the linker (and fail loudly if something does call them).
+static int no_engine() {
+  fprintf(stderr, "fuzz_host: engine entry point called\n");
+  abort();
+}
+const char* tcrc_last_error(void) { return "no engine in this driver"; }
+uint32_t tcrc_mask(uint32_t crc) { return ((crc >> 15) | (crc << 17)) + 0xa282ead8u; }
+uint32_t tcrc_unmask(uint32_t m) {
+  const uint32_t rot = m - 0xa282ead8u;
+  return (rot >> 17) | (rot << 15);
+}
+void* tcrc_host_alloc(tcrc_ctx*, size_t n) { return malloc(n ? n : 1); }
+void tcrc_host_free(tcrc_ctx*, void* p) { free(p); }
+int tcrc_host_batch_stamp(tcrc_ctx*, const void*, uint64_t, const tcrc_desc*, uint64_t, const uint8_t*, uint32_t, uint32_t*) { return no_engine(); }
+int tcrc_host_batch_verify(tcrc_ctx*, const void*, uint64_t, const tcrc_desc*, uint64_t, const uint8_t*, uint32_t, const uint32_t*, uint32_t*, uint8_t*, uint64_t*) { return no_engine(); }
+int tcrc_host_wal_verify(tcrc_ctx*, const void*, uint64_t, uint64_t, tcrc_wal_block*, uint64_t*, uint64_t*) { return no_engine(); }
+int tcrc_extend(tcrc_ctx*, uint32_t, const void*, size_t, uint32_t*) { return no_engine(); }
+}
+
+using namespace terarkdb_amd;
+
+namespace {
+
+std::mt19937_64 rng(12345);
+uint64_t rnd(uint64_t n) { return n ? rng() % n : 0; }
+
+struct OracleStamper : log::RecordStamper {
+  Status Stamp(const char* base, size_t, const tcrc_desc* spans, size_t n, uint32_t* out) override {
+    for (size_t i = 0; i < n; ++i)
+      out[i] = oracle_crc32c_mask(oracle_crc32c_extend(0, base + spans[i].offset, spans[i].len));
+    return Status::OK();
+  }
+};
+
+struct OracleVerifier : log::RecordVerifier {
+  Status ScanBlocks(const char* img, size_t n, uint64_t log_number, tcrc_wal_block* blocks) override {
+    oracle_wal_scan_blocks(reinterpret_cast<const uint8_t*>(img), n, log_number, reinterpret_cast<uint32_t*>(blocks));
+    return Status::OK();
+  }
+};
+
+struct CountingReporter : log::Reader::Reporter {
+  size_t dropped = 0, calls = 0;
+  void Corruption(size_t bytes, const Status&) override {
+    dropped += bytes;
+    ++calls;
+  }
+};
+
+// Checker that computes real checksums (honest) or declares every block good (credulous).
+struct FuzzChecker : BlockBatchChecker {
+  bool credulous;
+  explicit FuzzChecker(bool c) : credulous(c) {}
+  Status Check(const char* image, size_t image_bytes, const tcrc_desc* spans, size_t n, uint32_t* computed, uint8_t* ok) override {
+    for (size_t i = 0; i < n; ++i) {
+      if (spans[i].offset + spans[i].len + 4 > image_bytes) {
+        fprintf(stderr, "span outside the image\n");
+        abort();
+      }
+      computed[i] = oracle_crc32c_mask(oracle_crc32c_extend(0, image + spans[i].offset, spans[i].len));
+      const uint32_t stored = DecodeFixed32(image + spans[i].offset + spans[i].len);
+      ok[i] = credulous || stored == computed[i];
+    }
+    return Status::OK();
+  }
+};
+
+void mutate(std::string* s, int flips) {
+  for (int i = 0; i < flips && !s->empty(); ++i) {
+    const size_t pos = rnd(s->size());
+    switch (rnd(4)) {
+      case 0: (*s)[pos] ^= static_cast<char>(1u << rnd(8)); break;
+      case 1: (*s)[pos] = static_cast<char>(rnd(256)); break;
+      case 2: (*s)[pos] = 0; break;
+      default: (*s)[pos] = static_cast<char>(0xff); break;
+    }
+  }
+}
+
+std::string make_log(bool recycle, uint64_t log_number, int records) {
+  auto file = std::make_shared<MemFile>();
+  OracleStamper stamper;
+  {
+    log::Writer w(std::unique_ptr<WritableFile>(new MemSink(file)), log_number, recycle, rnd(2) != 0, &stamper);
+    for (int i = 0; i < records; ++i) {
+      const size_t len = rnd(10) == 0 ? rnd(90000) : rnd(300);
+      std::string rec(len, static_cast<char>('a' + i % 26));
+      w.AddRecord(Slice(rec));
+    }
+    w.WriteBuffer();
+  }
+  return file->contents;
+}
+
+int fuzz_log_reader(int iterations) {
+  OracleVerifier verifier;
+  for (int it = 0; it < iterations; ++it) {
+    const bool recycle = rnd(2) != 0;
+    const uint64_t log_number = 1 + rnd(5);
+    auto file = std::make_shared<MemFile>();
+    file->contents = make_log(recycle, log_number, 1 + static_cast<int>(rnd(40)));
+    const size_t clean_size = file->contents.size();
+    if (rnd(4) != 0) mutate(&file->contents, 1 + static_cast<int>(rnd(6)));
+    if (rnd(3) == 0) file->contents.resize(rnd(file->contents.size() + 1));  // truncation
+    if (rnd(5) == 0) file->contents.append(std::string(rnd(70000), '\0'));  // preallocated tail
+    CountingReporter rep;
+    log::Reader reader(std::unique_ptr<SequentialFile>(new MemSource(file)), &rep, rnd(8) != 0, log_number, false,
+                       &verifier);
+    if (rnd(2)) {
+      auto image = std::make_shared<log::VerifiedLogImage>();
+      log::VerifyLogImage(&verifier, file->contents.data(), file->contents.size(), log_number, image.get());
+      reader.AttachVerifiedImage(image);
+    }
+    const WALRecoveryMode mode = static_cast<WALRecoveryMode>(rnd(3));  // the fourth mode can spin in the reference too
+    std::string scratch;
+    Slice record;
+    size_t returned = 0, n = 0;
+    while (reader.ReadRecord(&record, &scratch, mode)) {
+      returned += record.size();
+      if (++n > 100000) {
+        fprintf(stderr, "reader does not terminate\n");
+        return 1;
+      }
+    }
+    if (returned > file->contents.size() + clean_size) {
+      fprintf(stderr, "reader returned more bytes than the file holds\n");
+      return 1;
+    }
+  }
+  return 0;
+}
+
+int fuzz_block_cursor(int iterations) {
+  for (int it = 0; it < iterations; ++it) {
+    std::string block(rnd(300), '\0');
+    for (char& c : block) c = static_cast<char>(rnd(3) ? rnd(8) : rnd(256));
+    for (int delta = 0; delta < 2; ++delta) {
+      BlockCursor c(Slice(block), delta != 0);
+      size_t n = 0;
+      while (c.Next()) {
+        if (c.value().data() < block.data() || c.value().data() + c.value().size() > block.data() + block.size()) {
+          fprintf(stderr, "cursor value outside the block\n");
+          return 1;
+        }
+        if (++n > block.size() + 1) {
+          fprintf(stderr, "cursor does not terminate\n");
+          return 1;
+        }
+      }
+    }
+  }
+  return 0;
+}
+
+int fuzz_footer_and_batches(int iterations) {
+  for (int it = 0; it < iterations; ++it) {
+    std::string tail(48 + rnd(30), '\0');
+    for (char& c : tail) c = static_cast<char>(rnd(256));
+    if (rnd(2)) {
+      const uint64_t magic = rnd(2) ? kBlockBasedTableMagicNumber : kLegacyBlockBasedTableMagicNumber;
+      memcpy(&tail[tail.size() - 8], &magic, 8);
+    }
+    Footer f;
+    Slice in(tail);
+    (void)f.DecodeFrom(&in);
+    std::string rec(12 + rnd(200), '\0');
+    for (char& c : rec) c = static_cast<char>(rnd(4) ? rnd(20) : rnd(256));
+    std::string row;
+    WriteBatchRow(Slice(rec), rnd(1000), rnd(2) != 0, &row);
+  }
+  return 0;
+}
+
+void put_varint(std::string* d, uint64_t v) {
+  while (v >= 128) {
+    d->push_back(static_cast<char>((v & 127) | 128));
+    v >>= 7;
+  }
+  d->push_back(static_cast<char>(v));
+}
+
+// key/value entries with restart interval 1 (every entry a restart point)
+std::string simple_block(const std::vector<std::pair<std::string, std::string>>& kv) {
+  std::string b;
+  std::vector<uint32_t> restarts;
+  for (const auto& e : kv) {
+    restarts.push_back(static_cast<uint32_t>(b.size()));
+    put_varint(&b, 0);
+    put_varint(&b, e.first.size());
+    put_varint(&b, e.second.size());
+    b += e.first + e.second;
+  }
+  if (restarts.empty()) restarts.push_back(0);
+  char buf[4];
+  for (uint32_t r : restarts) {
+    EncodeFixed32(buf, r);
+    b.append(buf, 4);
+  }
+  EncodeFixed32(buf, static_cast<uint32_t>(restarts.size()));
+  b.append(buf, 4);
+  return b;
+}
+
+std::string handle(uint64_t off, uint64_t size) {
+  std::string h;
+  put_varint(&h, off);
+  put_varint(&h, size);
+  return h;
+}
+
+std::string make_table(int n_data, bool two_level) {
+  std::string file;
+  auto write = [&](const std::string& contents) {
+    const uint64_t off = file.size();
+    file += contents;
+    file.push_back('\0');
+    const uint32_t crc = oracle_crc32c_mask(oracle_crc32c_extend(0, file.data() + off, contents.size() + 1));
+    char buf[4];
+    EncodeFixed32(buf, crc);
+    file.append(buf, 4);
+    return std::make_pair(off, static_cast<uint64_t>(contents.size()));
+  };
+  std::vector<std::pair<std::string, std::string>> index;
+  for (int i = 0; i < n_data; ++i) {
+    std::string data(100 + rnd(3000), static_cast<char>(i));
+    auto h = write(data);
+    char key[16];
+    snprintf(key, sizeof(key), "k%08d", i);
+    index.emplace_back(key, handle(h.first, h.second));
+  }
+  std::pair<uint64_t, uint64_t> index_handle;
+  if (two_level) {
+    std::vector<std::pair<std::string, std::string>> top;
+    for (size_t p0 = 0; p0 < index.size(); p0 += 4) {
+      std::vector<std::pair<std::string, std::string>> part(index.begin() + p0, index.begin() + std::min(index.size(), p0 + 4));
+      auto h = write(simple_block(part));
+      top.emplace_back(part.back().first, handle(h.first, h.second));
+    }
+    index_handle = write(simple_block(top));
+  } else {
+    index_handle = write(simple_block(index));
+  }
+  std::string type(4, '\0');
+  type[0] = two_level ? 2 : 0;
+  auto props = write(simple_block({{"rocksdb.block.based.table.index.type", type},
+                                   {"rocksdb.index.value.is.delta.encoded", std::string(1, '\0')}}));
+  auto meta = write(simple_block({{"rocksdb.properties", handle(props.first, props.second)}}));
+  Footer f;
+  f.version = 2;
+  f.checksum = kCRC32c;
+  f.metaindex_handle.offset = meta.first;
+  f.metaindex_handle.size = meta.second;
+  f.index_handle.offset = index_handle.first;
+  f.index_handle.size = index_handle.second;
+  f.EncodeTo(&file, false);
+  return file;
+}
+
+int fuzz_table_verify(int iterations) {
+  for (int it = 0; it < iterations; ++it) {
+    auto file = std::make_shared<MemFile>();
+    file->contents = make_table(static_cast<int>(rnd(30)), rnd(2) != 0);
+    const bool clean = rnd(5) == 0;
+    if (!clean) mutate(&file->contents, 1 + static_cast<int>(rnd(8)));
+    if (!clean && rnd(6) == 0) file->contents.resize(rnd(file->contents.size() + 1));
+    for (int credulous = 0; credulous < 2; ++credulous) {
+      FuzzChecker checker(credulous != 0);
+      MemRandomAccessFile ra(file);
+      SstVerifyOptions opt;
+      opt.extent_bytes = 1u << 20;
+      opt.read_threads = 1 + static_cast<int>(rnd(3));
+      SstVerifyStats st;
+      Status s = VerifySstFileChecksum(&checker, &ra, "fuzz.sst", opt, &st);
+      if (clean && !s.ok()) {
+        fprintf(stderr, "clean table rejected: %s\n", s.ToString().c_str());
+        return 1;
+      }
+    }
+  }
+  return 0;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  const int scale = argc > 1 ? atoi(argv[1]) : 1;
+  if (fuzz_log_reader(300 * scale)) return 1;
+  if (fuzz_block_cursor(20000 * scale)) return 1;
+  if (fuzz_footer_and_batches(20000 * scale)) return 1;
+  if (fuzz_table_verify(400 * scale)) return 1;
+  printf("fuzz_host ok\n");
+  return 0;
+}
