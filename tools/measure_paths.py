@@ -276,6 +276,56 @@ def main():
         "note": "H2D of 1 GiB + kernel + D2H of 512 KiB of trailers; bounded by the host link (PCIe Gen5 x16, 63 GB/s spec)",
     }
 
+    # ---- config 2 with the block sizes a table builder really produces: 4 KiB and 8 KiB blocks that overshoot
+    #      by up to one entry, packed back to back with their 5-byte trailers (descriptor list, general path) -----------
+    for target in (4096, 8192):
+        rng2 = np.random.default_rng(target)
+        nblk = (1 << 30) // (target + 133)
+        # a block is closed once it passes block_size (table/flush_block_policy.cc:34-67): size in
+        # [block_size, block_size + one entry)
+        lens = (target + rng2.integers(0, 257, nblk)).astype(np.uint32)
+        offs = np.concatenate([[0], np.cumsum(lens.astype(np.uint64) + 5)[:-1]]).astype(np.uint64)
+        total = int(offs[-1] + lens[-1] + 5)
+        image = G.splitmix_dev((total + 7) // 8 * 8, 31)
+        types = torch.zeros(nblk, dtype=torch.uint8, device="cuda")
+        d_stamp = capi.make_desc_tensor(offs, lens, np.zeros(nblk, np.uint32), "cuda")
+        d_check = capi.make_desc_tensor(offs, lens + 1, np.zeros(nblk, np.uint32), "cuda")
+        vcounts = torch.zeros(3, dtype=torch.int64, device="cuda")
+
+        def t_stamp():
+            eng.batch_stamp(image, d_stamp, nblk, None, suffix=types, flags=capi.F_MASK | capi.F_STORE_AFTER)
+
+        def t_verify():
+            eng.batch_verify(image, d_check, nblk, vcounts, flags=capi.F_EXPECT_AFTER)
+
+        out_t = {}
+        for name, fn in (("stamp_in_place", t_stamp), ("verify", t_verify)):
+            for _ in range(30):
+                fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(50):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 50
+            out_t[name + "_us"] = round(ms * 1e3, 1)
+            out_t[name + "_GBps"] = round(float(lens.sum() + nblk) / ms / 1e6, 1)
+        eng.counts_reset(vcounts)
+        t_verify()
+        cc = vcounts.cpu().numpy()
+        assert int(cc[0]) == 0 and int(cc[2]) == nblk
+        sample = rng2.integers(0, nblk, 200)
+        img_h = image.cpu().numpy()
+        for i_ in sample:
+            o_, l_ = int(offs[i_]), int(lens[i_])
+            want_crc = O.mask(O.extend(O.value(img_h[o_:o_ + l_]), b"\0"))
+            assert int(img_h[o_ + l_ + 1:o_ + l_ + 5].copy().view("<u4")[0]) == want_crc
+        out_t.update({"blocks": int(nblk), "image_bytes": total, "mean_block": target})
+        res[f"config2_variable_blocks_{target}"] = out_t
+        del image, img_h
+
     # ---- config 3: mixed-size log, >= 256 MiB, both header kinds, with seeded bit flips ------------
     for recycle in (0, 1):
         tl = O.OracleLog(recycle=bool(recycle), log_number=123)
