@@ -171,3 +171,11 @@ def test_verify_db_module_under_torchrun(tmp_path):
     p = subprocess.run([sys.executable, "-m", "terarkdb_amd.verify_db", str(d)], capture_output=True, text=True,
                        timeout=240, cwd=ROOT)
     assert p.returncode == 1 and ("%s is corrupted: %s" % (lays[3].path, S.expected_status(lays[3]))) in p.stdout
+
+
+def test_integration_example_program(tmp_path):
+    """The call sequences of the integration guide, compiled and run as one program."""
+    exe = os.path.join(ROOT, "terarkdb_amd", "bin", "integration_example")
+    p = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "integration example ok" in p.stdout and "verdicts from one device pass" in p.stdout
