@@ -34,7 +34,11 @@ extern "C" {
 typedef struct tcrc_ctx tcrc_ctx;
 
 /* One buffer of a batch: bytes [offset, offset+len) of the batch's base pointer,
- * checksummed as Extend(init, ...).  init = 0 gives Value(). */
+ * checksummed as Extend(init, ...).  init = 0 gives Value().  len may be up to 1 GiB
+ * (longer inputs: tcrc_dev_extend_long, tcrc_extend).  The host-pointer entry points
+ * reject a longer descriptor with TCRC_ERR_TOO_LARGE; the device-pointer ones cannot
+ * see the descriptors, so there the kernel reads nothing for such a descriptor, its
+ * output value is unspecified and a verify counts it as a mismatch. */
 typedef struct tcrc_desc {
   uint64_t offset;
   uint32_t len;

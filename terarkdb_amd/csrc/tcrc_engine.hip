@@ -8,13 +8,15 @@
 //   and Z_D is four table lookups (one per state byte).  The tables live in LDS,
 //   replicated 32 times with the replica index in the bank bits, so that lane l
 //   only ever touches bank (l mod 32): every ds_read_b32 is conflict-free
-//   whatever the data is.  Rows are laid out so that the buffer ENDS on a row
-//   boundary; missing leading bytes are zeros, which do not change a CRC
-//   remainder, and the initial register is XORed into the first four message
-//   bytes.  After the last row the 4*G states are reduced to one register with
-//   log2(G)+4 more (unreplicated) table steps and wave shuffles.
-//   Loads are 16 bytes per lane, 128*G/8 contiguous bytes per group, so each
-//   wave instruction fetches whole 128-byte lines.
+//   whatever the data is.  Rows are aligned to D-byte ADDRESS boundaries, so every
+//   lane load is an aligned 16-byte load and each wave instruction fetches whole
+//   128-byte lines wherever a buffer starts.  The bytes of the first row before the
+//   message are zeroed (leading zeros do not change a CRC remainder) and the
+//   initial register is XORed into the first four message bytes; the bytes of the
+//   last row after the message are zeroed too and taken back out at the end by one
+//   multiplication with x^(-8 * their count).  After the last row the 4*G states
+//   are reduced to one register with log2(G)+4 more (unreplicated) table steps and
+//   wave shuffles.
 //
 // What it computes is the reference's crc32c::Extend (util/crc32c.cc:356-398,
 // 1226-1228), Mask (util/crc32c.h:38-41), the SST trailer rule
@@ -39,6 +41,8 @@ constexpr int kThreads = 1024;       // one workgroup per CU (LDS-bound), 16 wav
 constexpr int kWavesPerWg = kThreads / 64;
 constexpr int kMainDwords = 32768;   // 4 tables x 256 entries x 32 replicas
 constexpr uint32_t kMaskDelta = 0xa282ead8u;
+// Longest span one lane group walks (row arithmetic is 32-bit); longer inputs go through the long-buffer path.
+constexpr uint32_t kMaxSpan = 1u << 30;
 
 template <int G> struct Geo;
 template <> struct Geo<4>  { static constexpr int kLog2 = 2; };
@@ -129,6 +133,7 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p) {
     const bool valid = buf < n;
     uint64_t off = 0;
     uint32_t len = 0, init = 0, item_index = 0;
+    bool oversize = false;
     const tcrc_desc dsc = d_next;
     if (p.desc) {
       const uint64_t nb = (round + nwaves) * GPW + grp;
@@ -139,6 +144,10 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p) {
         off = dsc.offset;
         len = dsc.len;
         init = dsc.init;
+        if (len > kMaxSpan) {  // not walked: nothing is read, a verify counts it as a mismatch
+          len = 0;
+          oversize = true;
+        }
         if (wal_items) {
           item_index = init;  // record index inside its 32 KiB block
           init = 0;
@@ -389,7 +398,7 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p) {
         }
       }
       if (p.verify) {
-        const bool good = stored == masked;
+        const bool good = stored == masked && !oversize;
         if (p.ok) p.ok[buf] = good ? 1 : 0;
         if (!good) {
           atomicAdd(&p.counts[TCRC_CNT_MISMATCH], 1ull);

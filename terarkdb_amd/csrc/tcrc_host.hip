@@ -26,7 +26,9 @@ int host_begin(tcrc_ctx* ctx) {  // the caller has made the context's GPU curren
 constexpr size_t kZcDescOff = tcrc_ctx::kZcData;
 constexpr size_t kZcSuffixOff = kZcDescOff + tcrc_ctx::kZcMaxItems * sizeof(tcrc_desc);
 constexpr size_t kZcOutOff = kZcSuffixOff + tcrc_ctx::kZcMaxItems;
-constexpr size_t kZcBytes = kZcOutOff + tcrc_ctx::kZcMaxItems * 4;
+constexpr size_t kZcExpectedOff = kZcOutOff + tcrc_ctx::kZcMaxItems * 4;
+constexpr size_t kZcOkOff = kZcExpectedOff + tcrc_ctx::kZcMaxItems * 4;
+constexpr size_t kZcBytes = kZcOkOff + tcrc_ctx::kZcMaxItems;
 // Above this many input bytes a copy to HBM pays for itself (the kernel reads host memory at link speed).
 constexpr size_t kZcMaxInput = (size_t)1 << 20;
 
@@ -106,6 +108,25 @@ int staged_upload(tcrc_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
   return TCRC_OK;
 }
 
+// Every descriptor must lie inside [0, base_bytes) together with the stored value the flags place
+// `after` bytes behind it or 6 bytes in front of it, and be short enough for one lane group.
+int check_descs(const tcrc_desc* d, uint64_t n, uint64_t base_bytes, uint64_t after, bool before) {
+  for (uint64_t i = 0; i < n; ++i) {
+    if (d[i].len > (1u << 30)) return fail(TCRC_ERR_TOO_LARGE, "descriptor above 1 GiB: use tcrc_dev_extend_long / tcrc_extend");
+    if (d[i].offset > base_bytes || d[i].len + after > base_bytes - d[i].offset)
+      return fail(TCRC_ERR_INVALID, after ? "descriptor (or its stored checksum) outside the buffer"
+                                          : "descriptor outside the buffer");
+    if (before && d[i].offset < 6) return fail(TCRC_ERR_INVALID, "descriptor leaves no room for the stored checksum before it");
+  }
+  return TCRC_OK;
+}
+
+// Small batches are served without copy commands when the input is short enough to bounce through the
+// zero-copy block or already lies in pinned memory.
+bool zero_copy_fits(const void* h_base, uint64_t base_bytes, uint64_t n) {
+  return n <= tcrc_ctx::kZcMaxItems && base_bytes <= kZcMaxInput && (base_bytes <= tcrc_ctx::kZcData || is_pinned(h_base));
+}
+
 int upload(tcrc_ctx* ctx, tcrc_scratch* s, const void* h, size_t bytes, size_t slack = 64) {
   if (int rc = scratch_reserve(ctx, s, bytes + slack)) return rc;
   ctx->st_host_bytes_in.fetch_add(bytes, std::memory_order_relaxed);
@@ -178,13 +199,12 @@ int tcrc_host_batch_stamp(tcrc_ctx* ctx, const void* h_base, uint64_t base_bytes
   if (n == 0) return TCRC_OK;
   if (!h_base || !h_desc || !h_out) return fail(TCRC_ERR_INVALID, "null argument");
   if (flags & TCRC_F_STORE_AFTER) return fail(TCRC_ERR_INVALID, "host entry points return the values: nothing to store into");
-  for (uint64_t i = 0; i < n; ++i)
-    if (h_desc[i].offset + h_desc[i].len > base_bytes) return fail(TCRC_ERR_INVALID, "descriptor outside the buffer");
+  if (int rc = check_descs(h_desc, n, base_bytes, 0, false)) return rc;
   HostCallTimer timer(ctx);
   std::lock_guard<std::mutex> lock(ctx->host_mu);
   TCRC_DEVICE_SCOPE(ctx);
   if (int rc = host_begin(ctx)) return rc;
-  if (n <= tcrc_ctx::kZcMaxItems && base_bytes <= kZcMaxInput && (base_bytes <= tcrc_ctx::kZcData || is_pinned(h_base))) {
+  if (zero_copy_fits(h_base, base_bytes, n)) {
     // Small batch: no copies.  The kernel reads the bytes where they are (pinned memory) or from the bounce
     // area, takes its descriptors from the zero-copy block and writes the results there.
     if (int rc = zc_begin(ctx)) return rc;
@@ -248,17 +268,45 @@ int tcrc_host_batch_verify(tcrc_ctx* ctx, const void* h_base, uint64_t base_byte
   h_counts[TCRC_CNT_CHECKED] = 0;
   if (n == 0) return TCRC_OK;
   if (!h_base || !h_desc) return fail(TCRC_ERR_INVALID, "null argument");
-  const uint64_t after = (flags & TCRC_F_EXPECT_AFTER) ? 4 : 0;
-  for (uint64_t i = 0; i < n; ++i) {
-    if (h_desc[i].offset + h_desc[i].len + after > base_bytes)
-      return fail(TCRC_ERR_INVALID, "descriptor (or its stored checksum) outside the buffer");
-    if ((flags & TCRC_F_EXPECT_BEFORE) && h_desc[i].offset < 6)
-      return fail(TCRC_ERR_INVALID, "descriptor leaves no room for the stored checksum before it");
-  }
+  if (int rc = check_descs(h_desc, n, base_bytes, (flags & TCRC_F_EXPECT_AFTER) ? 4 : 0,
+                           (flags & TCRC_F_EXPECT_BEFORE) != 0))
+    return rc;
   HostCallTimer timer(ctx);
   std::lock_guard<std::mutex> lock(ctx->host_mu);
   TCRC_DEVICE_SCOPE(ctx);
   if (int rc = host_begin(ctx)) return rc;
+  if (zero_copy_fits(h_base, base_bytes, n)) {
+    // Small batch (one block fetched by a read, a handful of meta blocks): no copy commands.  The kernel
+    // reads the bytes where they lie or from the bounce area and leaves values and verdicts in the
+    // zero-copy block; the three counters are derived from the verdicts here, so that the kernel's own
+    // counter updates (atomics) stay in device memory.
+    if (int rc = zc_begin(ctx)) return rc;
+    if (int rc = scratch_reserve(ctx, &ctx->host_aux, 64)) return rc;
+    const void* base = nullptr;
+    if (!is_pinned(h_base, &base)) {
+      memcpy(ctx->zc, h_base, base_bytes);
+      base = ctx->zc;
+    }
+    memcpy(ctx->zc + kZcDescOff, h_desc, n * sizeof(tcrc_desc));
+    if (h_suffix) memcpy(ctx->zc + kZcSuffixOff, h_suffix, n);
+    if (h_expected) memcpy(ctx->zc + kZcExpectedOff, h_expected, n * 4);
+    const uint8_t* ok = (const uint8_t*)(ctx->zc + kZcOkOff);
+    if (int rc = tcrc_dev_batch_verify(ctx, base, (const tcrc_desc*)(ctx->zc + kZcDescOff), n,
+                                       h_suffix ? (const uint8_t*)(ctx->zc + kZcSuffixOff) : nullptr, flags,
+                                       h_expected ? (const uint32_t*)(ctx->zc + kZcExpectedOff) : nullptr,
+                                       (uint32_t*)(ctx->zc + kZcOutOff), (uint8_t*)(ctx->zc + kZcOkOff),
+                                       (uint64_t*)ctx->host_aux.p, ctx->host_stream))
+      return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->host_stream));
+    if (h_out) memcpy(h_out, ctx->zc + kZcOutOff, n * 4);
+    if (h_ok) memcpy(h_ok, ok, n);
+    for (uint64_t i = 0; i < n; ++i)
+      if (!ok[i]) {
+        if (h_counts[TCRC_CNT_MISMATCH]++ == 0) h_counts[TCRC_CNT_FIRST_BAD] = i;
+      }
+    h_counts[TCRC_CNT_CHECKED] = n;
+    return TCRC_OK;
+  }
   if (int rc = upload(ctx, &ctx->host_data, h_base, base_bytes)) return rc;
   if (int rc = upload(ctx, &ctx->host_desc, h_desc, n * sizeof(tcrc_desc))) return rc;
   // host_aux layout: [counts 3 x u64][suffix n][pad][expected n x u32][ok n]
