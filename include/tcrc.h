@@ -161,6 +161,15 @@ typedef struct tcrc_wal_block {
 int tcrc_dev_wal_verify(tcrc_ctx* ctx, const void* d_img, uint64_t size, uint64_t log_number, tcrc_wal_block* d_blocks,
                         uint64_t* d_counts, uint64_t* h_records, void* stream);
 
+/* The same for one part of a log that is verified piece by piece (a file streamed through a staging
+ * buffer): d_part holds the bytes from block `first_block` of the file on, `size` of them - whole 32 KiB
+ * blocks when more_follows != 0, in which case the part's last block is not treated as the end of the
+ * file (db/log_reader.cc:276-312 only reports a truncated header or record at the real end).
+ * d_blocks[b] describes block first_block + b; TCRC_CNT_FIRST_BAD counts blocks from the file's start. */
+int tcrc_dev_wal_verify_part(tcrc_ctx* ctx, const void* d_part, uint64_t size, uint64_t log_number,
+                             uint64_t first_block, int more_follows, tcrc_wal_block* d_blocks, uint64_t* d_counts,
+                             uint64_t* h_records, void* stream);
+
 /* One physical record of a log image, as ReadPhysicalRecord would meet it. */
 #define TCRC_WAL_REC_BAD 0     /* checksum mismatch: the reference drops the rest of the block here */
 #define TCRC_WAL_REC_OK 1      /* checksum matches and no earlier record of the block failed */
@@ -218,6 +227,12 @@ int tcrc_host_batch_verify(tcrc_ctx* ctx, const void* h_base, uint64_t base_byte
 /* Host form of tcrc_dev_wal_verify: h_blocks gets ceil(size/32768) entries. */
 int tcrc_host_wal_verify(tcrc_ctx* ctx, const void* h_img, uint64_t size, uint64_t log_number, tcrc_wal_block* h_blocks,
                          uint64_t* h_counts, uint64_t* h_records);
+
+/* Host form of tcrc_dev_wal_verify_part.  h_counts is ACCUMULATED into (initialise it to {0, ~0, 0} before
+ * the first part), so that the parts of one file add up to what tcrc_host_wal_verify reports for it. */
+int tcrc_host_wal_verify_part(tcrc_ctx* ctx, const void* h_part, uint64_t size, uint64_t log_number,
+                              uint64_t first_block, int more_follows, tcrc_wal_block* h_blocks, uint64_t* h_counts,
+                              uint64_t* h_records);
 
 /* Host form of verify + list: h_blocks (may be NULL) as in tcrc_host_wal_verify, then the record list. */
 int tcrc_host_wal_list(tcrc_ctx* ctx, const void* h_img, uint64_t size, uint64_t log_number, tcrc_wal_block* h_blocks,

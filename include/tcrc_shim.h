@@ -120,6 +120,16 @@ int tcrc_shim_dump_wal(tcrc_ctx* ctx, const char* path, int print_header, int pr
 int tcrc_shim_dump_wal_cb(tcrc_shim_scan_fn fn, void* user, const char* path, int print_header, int print_values,
                           char* out, size_t out_cap, size_t* out_len, char* err, size_t err_cap, size_t* err_len);
 
+/* Checks every physical record of one log file the way recovery's reader meets it (db/log_reader.cc:276-406
+ * with checksum = true): the file is read in pieces of extent_bytes (0 = default 64 MiB) with read_threads
+ * (0 = default) positional reads each, the read of one piece overlapping the engine's work on the previous one.
+ * blocks_out (may be NULL) receives up to blocks_cap entries, one per 32 KiB block.  report_out (may be NULL)
+ * receives 5 values: file bytes, physical records, records with a checksum mismatch, first 32 KiB block holding
+ * one (~0 if none), TCRC_WAL_END_* of the file's last block.  Returns 0, or -1 with the Status text in message. */
+int tcrc_shim_wal_verify_file(tcrc_ctx* ctx, const char* path, uint64_t log_number, size_t extent_bytes,
+                              int read_threads, tcrc_wal_block* blocks_out, size_t blocks_cap, uint64_t* report_out,
+                              char* message, size_t message_cap);
+
 /* File-level DBImpl::VerifyChecksum (db/db_impl.cc:4657-4690) over a database directory: every NNNNNN.sst in
  * file-number order (stopping at the first corrupt one, whose name goes to bad_file and whose status to
  * message), then a checksum scan of NNNNNN.log and MANIFEST-NNNNNN.  Files are dealt to shard_index of

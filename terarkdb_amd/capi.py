@@ -68,6 +68,8 @@ SIGNATURES.update({
     "tcrc_host_blocks_stamp": (_i, [_vp, _vp, _u64, _u32, _u64, _u32, _i, _u32, _vp]),
     "tcrc_host_batch_verify": (_i, [_vp, _vp, _u64, _vp, _u64, _vp, _u32, _vp, _vp, _vp, _vp]),
     "tcrc_host_wal_verify": (_i, [_vp, _vp, _u64, _u64, _vp, _vp, C.POINTER(_u64)]),
+    "tcrc_host_wal_verify_part": (_i, [_vp, _vp, _u64, _u64, _u64, _i, _vp, _vp, C.POINTER(_u64)]),
+    "tcrc_dev_wal_verify_part": (_i, [_vp, _vp, _u64, _u64, _u64, _i, _vp, _vp, C.POINTER(_u64), _vp]),
     "tcrc_dev_wal_frame": (_i, [_vp, _vp, _vp, _u64, _u64, _i, _u32, _vp, _u64, C.POINTER(_u64), C.POINTER(_u32),
                                 C.POINTER(_u64), _vp]),
     "tcrc_wal_framed_size": (_u64, [_vp, _u64, _i, _u32]),
@@ -121,6 +123,7 @@ SIGNATURES.update({
                                    C.POINTER(_sz)]),
     "tcrc_shim_footer_encode": (_i, [_i, _u32, _i, _u64, _u64, _u64, _u64, _vp]),
     "tcrc_shim_footer_decode": (_i, [_vp, _sz, C.POINTER(_i), C.POINTER(_u32), C.POINTER(_u64), _vp, C.c_char_p, _sz]),
+    "tcrc_shim_wal_verify_file": (_i, [_vp, C.c_char_p, _u64, _sz, _i, _vp, _sz, _vp, C.c_char_p, _sz]),
     "tcrc_shim_verify_db": (_i, [_vp, C.c_char_p, _u32, _u32, C.POINTER(_u64), C.c_char_p, _sz, C.c_char_p, _sz]),
     "tcrc_shim_file_checksum": (_i, [_vp, C.c_char_p, _u64, _sz, C.POINTER(_u32), C.POINTER(_u64), C.c_char_p, _sz]),
     "tcrc_shim_copy_file": (_i, [_vp, C.c_char_p, C.c_char_p, _u64, _sz, _i, C.POINTER(_u32), C.POINTER(_u64),

@@ -332,31 +332,47 @@ int tcrc_host_batch_verify(tcrc_ctx* ctx, const void* h_base, uint64_t base_byte
 
 int tcrc_host_wal_verify(tcrc_ctx* ctx, const void* h_img, uint64_t size, uint64_t log_number,
                          tcrc_wal_block* h_blocks, uint64_t* h_counts, uint64_t* h_records) {
-  if (!ctx) return fail(TCRC_ERR_INVALID, "null context");
-  if (h_records) *h_records = 0;
   if (h_counts) {
     h_counts[TCRC_CNT_MISMATCH] = 0;
     h_counts[TCRC_CNT_FIRST_BAD] = ~0ull;
     h_counts[TCRC_CNT_CHECKED] = 0;
   }
+  return tcrc_host_wal_verify_part(ctx, h_img, size, log_number, 0, 0, h_blocks, h_counts, h_records);
+}
+
+int tcrc_host_wal_verify_part(tcrc_ctx* ctx, const void* h_part, uint64_t size, uint64_t log_number,
+                              uint64_t first_block, int more_follows, tcrc_wal_block* h_blocks, uint64_t* h_counts,
+                              uint64_t* h_records) {
+  if (!ctx) return fail(TCRC_ERR_INVALID, "null context");
+  if (h_records) *h_records = 0;
+  if (more_follows && size % 32768 != 0)
+    return fail(TCRC_ERR_INVALID, "a part that is not the end of the log must be whole 32 KiB blocks");
   if (size == 0) return TCRC_OK;
-  if (!h_img || !h_blocks) return fail(TCRC_ERR_INVALID, "null argument");
+  if (!h_part || !h_blocks) return fail(TCRC_ERR_INVALID, "null argument");
   HostCallTimer timer(ctx);
   std::lock_guard<std::mutex> lock(ctx->host_mu);
   TCRC_DEVICE_SCOPE(ctx);
   if (int rc = host_begin(ctx)) return rc;
   const uint64_t nblocks = (size + 32767) / 32768;
-  if (int rc = upload(ctx, &ctx->host_data, h_img, size)) return rc;
+  if (int rc = upload(ctx, &ctx->host_data, h_part, size)) return rc;
   if (int rc = scratch_reserve(ctx, &ctx->host_blocks, nblocks * sizeof(tcrc_wal_block))) return rc;
   if (int rc = scratch_reserve(ctx, &ctx->host_aux, 64)) return rc;
   if (int rc = tcrc_dev_counts_reset(ctx, (uint64_t*)ctx->host_aux.p, ctx->host_stream)) return rc;
-  if (int rc = tcrc_dev_wal_verify(ctx, ctx->host_data.p, size, log_number, (tcrc_wal_block*)ctx->host_blocks.p,
-                                   (uint64_t*)ctx->host_aux.p, h_records, ctx->host_stream))
+  if (int rc = tcrc_dev_wal_verify_part(ctx, ctx->host_data.p, size, log_number, first_block, more_follows,
+                                        (tcrc_wal_block*)ctx->host_blocks.p, (uint64_t*)ctx->host_aux.p, h_records,
+                                        ctx->host_stream))
     return rc;
   HIP_TRY(hipMemcpyAsync(h_blocks, ctx->host_blocks.p, nblocks * sizeof(tcrc_wal_block), hipMemcpyDeviceToHost,
                          ctx->host_stream));
-  if (h_counts) HIP_TRY(hipMemcpyAsync(h_counts, ctx->host_aux.p, 24, hipMemcpyDeviceToHost, ctx->host_stream));
+  uint64_t part_counts[TCRC_CNT_WORDS] = {0, ~0ull, 0};
+  if (h_counts) HIP_TRY(hipMemcpyAsync(part_counts, ctx->host_aux.p, 24, hipMemcpyDeviceToHost, ctx->host_stream));
   HIP_TRY(hipStreamSynchronize(ctx->host_stream));
+  if (h_counts) {
+    h_counts[TCRC_CNT_MISMATCH] += part_counts[TCRC_CNT_MISMATCH];
+    if (part_counts[TCRC_CNT_FIRST_BAD] < h_counts[TCRC_CNT_FIRST_BAD])
+      h_counts[TCRC_CNT_FIRST_BAD] = part_counts[TCRC_CNT_FIRST_BAD];
+    h_counts[TCRC_CNT_CHECKED] += part_counts[TCRC_CNT_CHECKED];
+  }
   return TCRC_OK;
 }
 

@@ -37,6 +37,7 @@ constexpr uint32_t kLongSpan = 4096;
 struct WalkParams {
   const uint8_t* img;
   uint64_t size;        // bytes in this image (the last block may be short)
+  uint32_t tail;        // the image ends where the file ends (0: more of the file follows this part)
   uint64_t log_number;
   uint32_t nblocks;
   tcrc_desc* items;  // short spans
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(256) void k_wal_walk(WalkParams p) {
   const bool have = blk < p.nblocks;
   const uint64_t base = (uint64_t)blk * kLogBlock;
   const uint64_t end = base + kLogBlock < p.size ? base + kLogBlock : p.size;
-  const bool last = end == p.size;
+  const bool last = p.tail && end == p.size;
   uint32_t n = 0, n_long = 0, code = TCRC_WAL_END_CLEAN, hs = 0, len = 0;
   uint64_t pos = base;
   if (have) {
@@ -441,8 +442,16 @@ extern "C" int tcrc_dev_wal_list(tcrc_ctx* ctx, const void* d_img, uint64_t size
 extern "C" int tcrc_dev_wal_verify(tcrc_ctx* ctx, const void* d_img, uint64_t size, uint64_t log_number,
                                    tcrc_wal_block* d_blocks, uint64_t* d_counts, uint64_t* h_records,
                                    void* stream) {
+  return tcrc_dev_wal_verify_part(ctx, d_img, size, log_number, 0, 0, d_blocks, d_counts, h_records, stream);
+}
+
+extern "C" int tcrc_dev_wal_verify_part(tcrc_ctx* ctx, const void* d_img, uint64_t size, uint64_t log_number,
+                                        uint64_t first_block, int more_follows, tcrc_wal_block* d_blocks,
+                                        uint64_t* d_counts, uint64_t* h_records, void* stream) {
   if (!ctx) return fail(TCRC_ERR_INVALID, "null context");
   if (h_records) *h_records = 0;
+  if (more_follows && size % kLogBlock != 0)
+    return fail(TCRC_ERR_INVALID, "a part that is not the end of the log must be whole 32 KiB blocks");
   if (size == 0) return TCRC_OK;
   if (!d_img || !d_blocks || !d_counts) return fail(TCRC_ERR_INVALID, "null argument");
   TCRC_DEVICE_SCOPE(ctx);
@@ -471,6 +480,7 @@ extern "C" int tcrc_dev_wal_verify(tcrc_ctx* ctx, const void* d_img, uint64_t si
       WalkParams w{};
       w.img = (const uint8_t*)d_img + off;
       w.size = bytes;
+      w.tail = (!more_follows && b0 + nb == nblocks_total) ? 1u : 0u;  // only the file's last block sees its end
       w.log_number = log_number;
       w.nblocks = nb;
       w.items = (tcrc_desc*)ctx->wal_items.p;
@@ -491,7 +501,7 @@ extern "C" int tcrc_dev_wal_verify(tcrc_ctx* ctx, const void* d_img, uint64_t si
       p.verify = 1;
       p.counts = misc + 2;
       p.wal_blocks = w.blocks;
-      p.wal_block_base = b0;
+      p.wal_block_base = first_block + b0;
       // short spans: four lanes each; the kernel takes min(capacity, descriptors written)
       p.desc = w.items;
       p.n = capacity;

@@ -38,15 +38,13 @@ Status ScanLogFile(tcrc_ctx* ctx, const std::string& path, DbVerifyReport* repor
   ++report->log_files;
   report->log_bytes += size;
   if (size == 0) return Status::OK();
-  char* img = static_cast<char*>(tcrc_host_alloc(ctx, size));
-  if (!img) return Status::IOError("checksum engine: cannot allocate pinned memory for " + path);
-  s = ParallelRead(file.get(), 0, size, img, 8);
-  std::vector<tcrc_wal_block> blocks((size + log::kBlockSize - 1) / log::kBlockSize);
-  uint64_t counts[TCRC_CNT_WORDS] = {0, 0, 0}, records = 0;
-  if (s.ok() && tcrc_host_wal_verify(ctx, img, size, LogNumberFromFileName(path), blocks.data(), counts, &records) != TCRC_OK)
-    s = Status::IOError(std::string("checksum engine: ") + tcrc_last_error());
-  tcrc_host_free(ctx, img);
+  log::DeviceRecordVerifier verifier(ctx);
+  log::VerifiedLogImage image;
+  s = log::VerifyLogFile(&verifier, file.get(), LogNumberFromFileName(path), &image);
   if (!s.ok()) return s;
+  const std::vector<tcrc_wal_block>& blocks = image.blocks;
+  const uint64_t records = image.records;
+  const uint64_t counts[TCRC_CNT_WORDS] = {image.mismatches, image.first_bad_block, image.records};
   report->log_records += records;
   report->log_bad_records += counts[TCRC_CNT_MISMATCH];
   const tcrc_wal_block& tail = blocks.back();

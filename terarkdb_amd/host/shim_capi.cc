@@ -3,6 +3,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
+
 #include <memory>
 #include <string>
 #include <vector>
@@ -412,6 +414,32 @@ int tcrc_shim_footer_decode(const void* tail, size_t n, int* checksum, uint32_t*
     handles4[1] = f.metaindex_handle.size;
     handles4[2] = f.index_handle.offset;
     handles4[3] = f.index_handle.size;
+  }
+  if (message && message_cap) snprintf(message, message_cap, "%s", s.ToString().c_str());
+  return s.ok() ? 0 : -1;
+}
+
+int tcrc_shim_wal_verify_file(tcrc_ctx* ctx, const char* path, uint64_t log_number, size_t extent_bytes,
+                              int read_threads, tcrc_wal_block* blocks_out, size_t blocks_cap, uint64_t* report_out,
+                              char* message, size_t message_cap) {
+  std::unique_ptr<RandomAccessFile> file;
+  Status s = NewPosixRandomAccessFile(path, &file);
+  log::VerifiedLogImage image;
+  if (s.ok()) {
+    log::DeviceRecordVerifier verifier(ctx);
+    log::LogFileScanOptions opt;
+    if (extent_bytes) opt.extent_bytes = extent_bytes;
+    if (read_threads > 0) opt.read_threads = read_threads;
+    s = log::VerifyLogFile(&verifier, file.get(), log_number, &image, opt);
+  }
+  if (s.ok()) {
+    if (blocks_out)
+      memcpy(blocks_out, image.blocks.data(), std::min(blocks_cap, image.blocks.size()) * sizeof(tcrc_wal_block));
+    if (report_out) {
+      const uint64_t v[5] = {image.size, image.records, image.mismatches, image.first_bad_block,
+                             image.blocks.empty() ? 0ull : image.blocks.back().end_code};
+      memcpy(report_out, v, sizeof(v));
+    }
   }
   if (message && message_cap) snprintf(message, message_cap, "%s", s.ToString().c_str());
   return s.ok() ? 0 : -1;

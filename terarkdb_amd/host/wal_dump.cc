@@ -190,7 +190,7 @@ void WriteBatchRow(const Slice& rep, uint64_t physical_offset, bool print_values
 
 Status DumpWalFile(log::RecordVerifier* verifier, const std::string& wal_file, bool print_header, bool print_values,
                    std::string* out, std::string* err) {
-  // Read the whole file once for the device pass, then again through the reader.
+  // The whole file goes through the device pass in large pieces, then the reader reads it again for the payloads.
   std::unique_ptr<RandomAccessFile> ra;
   Status s = NewPosixRandomAccessFile(wal_file, &ra);
   if (!s.ok()) {
@@ -198,21 +198,9 @@ Status DumpWalFile(log::RecordVerifier* verifier, const std::string& wal_file, b
     return s;
   }
   const uint64_t log_number = LogNumberFromFileName(wal_file);
-  const size_t size = static_cast<size_t>(ra->Size());
-  std::vector<char> img(size ? size : 1);
-  size_t done = 0;
-  while (done < size) {
-    Slice got;
-    s = ra->Read(done, size - done, &got, img.data() + done);
-    if (!s.ok()) return s;
-    if (got.size() == 0) break;
-    if (got.data() != img.data() + done) memcpy(img.data() + done, got.data(), got.size());
-    done += got.size();
-  }
   auto image = std::make_shared<log::VerifiedLogImage>();
-  s = log::VerifyLogImage(verifier, img.data(), done, log_number, image.get());
+  s = log::VerifyLogFile(verifier, ra.get(), log_number, image.get());
   if (!s.ok()) return s;
-  std::vector<char>().swap(img);
 
   std::unique_ptr<SequentialFile> file;
   s = NewPosixSequentialFile(wal_file, &file);

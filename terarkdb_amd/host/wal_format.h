@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "../../include/tcrc.h"
+#include "files.h"
 #include "status.h"
 
 namespace terarkdb_amd {
@@ -48,6 +49,15 @@ class RecordVerifier {
   // img[0..n) starts at a record boundary that is taken as the start of a 32 KiB block;
   // blocks[b] describes bytes [32768 b, 32768 (b+1)).
   virtual Status ScanBlocks(const char* img, size_t n, uint64_t log_number, tcrc_wal_block* blocks) = 0;
+  // One part of a log that is checked piece by piece: img holds the file's bytes from block first_block on,
+  // whole 32 KiB blocks when more_follows (the part's last block is then not the end of the file).
+  // counts (TCRC_CNT_*, may be NULL) is accumulated into, with block indices counted from the file's start.
+  // An implementation without this returns NotSupported and callers check the whole image at once.
+  virtual Status ScanBlocksPart(const char* img, size_t n, uint64_t log_number, uint64_t first_block, bool more_follows,
+                                tcrc_wal_block* blocks, uint64_t* counts);
+  // Memory that file extents are read into (pinned for the device implementation).
+  virtual char* AllocStaging(size_t bytes);
+  virtual void FreeStaging(char* p);
 };
 
 class DeviceRecordStamper : public RecordStamper {
@@ -65,6 +75,10 @@ class DeviceRecordVerifier : public RecordVerifier {
  public:
   explicit DeviceRecordVerifier(tcrc_ctx* ctx) : ctx_(ctx) {}
   Status ScanBlocks(const char* img, size_t n, uint64_t log_number, tcrc_wal_block* blocks) override;
+  Status ScanBlocksPart(const char* img, size_t n, uint64_t log_number, uint64_t first_block, bool more_follows,
+                        tcrc_wal_block* blocks, uint64_t* counts) override;
+  char* AllocStaging(size_t bytes) override;
+  void FreeStaging(char* p) override;
 
  private:
   tcrc_ctx* ctx_;
@@ -76,8 +90,22 @@ struct VerifiedLogImage {
   uint64_t size = 0;  // bytes of the file that were verified
   std::vector<tcrc_wal_block> blocks;
   uint64_t records = 0;
+  // filled by VerifyLogFile with the device verifier: records whose checksum does not match (all of them,
+  // also those behind the first bad one of a block) and the first 32 KiB block that holds one (~0: none)
+  uint64_t mismatches = 0;
+  uint64_t first_bad_block = ~0ull;
 };
 Status VerifyLogImage(RecordVerifier* verifier, const char* img, size_t n, uint64_t log_number, VerifiedLogImage* out);
+
+struct LogFileScanOptions {
+  size_t extent_bytes = 64u << 20;  // the file is read and submitted in pieces of this size
+  int read_threads = 8;             // positional reads that fill one piece
+};
+// Reads a whole log file and checks it, the way recovery meets it (db/log_reader.cc:276-312 reads it block by
+// block; here the blocks go to the engine in large pieces).  The read of piece k+1 runs while the engine works
+// on piece k.  Nothing of the file is kept: a Reader given the result reads the file again for the payloads.
+Status VerifyLogFile(RecordVerifier* verifier, const RandomAccessFile* file, uint64_t log_number, VerifiedLogImage* out,
+                     const LogFileScanOptions& options = LogFileScanOptions());
 
 }  // namespace log
 }  // namespace terarkdb_amd

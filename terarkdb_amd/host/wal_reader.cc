@@ -1,5 +1,9 @@
 #include "wal_reader.h"
 
+#include <memory>
+#include <new>
+#include <thread>
+
 #include <stdio.h>
 #include <string.h>
 
@@ -313,6 +317,76 @@ Status VerifyLogImage(RecordVerifier* verifier, const char* img, size_t n, uint6
   if (s.ok())
     for (const tcrc_wal_block& b : out->blocks) out->records += b.n_records;
   return s;
+}
+
+Status RecordVerifier::ScanBlocksPart(const char*, size_t, uint64_t, uint64_t, bool, tcrc_wal_block*, uint64_t*) {
+  return Status::NotSupported("this verifier checks whole images only");
+}
+char* RecordVerifier::AllocStaging(size_t bytes) { return new (std::nothrow) char[bytes ? bytes : 1]; }
+void RecordVerifier::FreeStaging(char* p) { delete[] p; }
+
+Status VerifyLogFile(RecordVerifier* verifier, const RandomAccessFile* file, uint64_t log_number, VerifiedLogImage* out,
+                     const LogFileScanOptions& options) {
+  const uint64_t size = file->Size();
+  out->size = size;
+  out->blocks.assign((size + kBlockSize - 1) / kBlockSize, tcrc_wal_block{0, 0xffffffffu, 0, 0});
+  out->records = 0;
+  out->mismatches = 0;
+  out->first_bad_block = ~0ull;
+  if (size == 0) return Status::OK();
+  uint64_t extent = options.extent_bytes / kBlockSize * kBlockSize;
+  if (extent < kBlockSize) extent = kBlockSize;
+  const size_t buf_bytes = static_cast<size_t>(size < extent ? size : extent);
+  const int nbuf = size > extent ? 2 : 1;
+  char* buf[2] = {nullptr, nullptr};
+  for (int i = 0; i < nbuf; ++i) {
+    buf[i] = verifier->AllocStaging(buf_bytes);
+    if (!buf[i]) {
+      if (i) verifier->FreeStaging(buf[0]);
+      return Status::IOError("cannot allocate staging memory for a log file");
+    }
+  }
+  auto piece = [&](uint64_t off) { return static_cast<size_t>(size - off < extent ? size - off : extent); };
+  uint64_t counts[TCRC_CNT_WORDS] = {0, ~0ull, 0};
+  Status read_status[2];
+  read_status[0] = ParallelRead(file, 0, piece(0), buf[0], options.read_threads);
+  Status s;
+  bool whole_only = false;
+  int k = 0;
+  for (uint64_t off = 0; off < size && s.ok(); ++k) {
+    const size_t bytes = piece(off);
+    const uint64_t next_off = off + bytes;
+    std::thread next;
+    if (next_off < size) {
+      const RandomAccessFile* f = file;
+      const size_t len = piece(next_off);
+      char* dst = buf[(k + 1) & 1];
+      Status* st = &read_status[(k + 1) & 1];
+      const int threads = options.read_threads;
+      next = std::thread([f, next_off, len, dst, st, threads] { *st = ParallelRead(f, next_off, len, dst, threads); });
+    }
+    s = read_status[k & 1];
+    if (s.ok()) {
+      s = verifier->ScanBlocksPart(buf[k & 1], bytes, log_number, off / kBlockSize, next_off < size,
+                                   out->blocks.data() + off / kBlockSize, counts);
+      if (k == 0 && s.code() == Status::kNotSupported) whole_only = true;
+    }
+    if (next.joinable()) next.join();
+    off = next_off;
+  }
+  for (int i = 0; i < nbuf; ++i) verifier->FreeStaging(buf[i]);
+  if (whole_only) {
+    // a verifier that takes whole images only (the test seams): one read, one call
+    std::unique_ptr<char[]> img(new char[size]);
+    s = ParallelRead(file, 0, static_cast<size_t>(size), img.get(), options.read_threads);
+    if (!s.ok()) return s;
+    return VerifyLogImage(verifier, img.get(), static_cast<size_t>(size), log_number, out);
+  }
+  if (!s.ok()) return s;
+  for (const tcrc_wal_block& b : out->blocks) out->records += b.n_records;
+  out->mismatches = counts[TCRC_CNT_MISMATCH];
+  out->first_bad_block = counts[TCRC_CNT_FIRST_BAD];
+  return Status::OK();
 }
 
 }  // namespace log
