@@ -121,7 +121,7 @@ int tcrc_shim_dump_wal_cb(tcrc_shim_scan_fn fn, void* user, const char* path, in
                           char* out, size_t out_cap, size_t* out_len, char* err, size_t err_cap, size_t* err_len);
 
 /* Checks every physical record of one log file the way recovery's reader meets it (db/log_reader.cc:276-406
- * with checksum = true): the file is read in pieces of extent_bytes (0 = default 64 MiB) with read_threads
+ * with checksum = true): the file is read in pieces of extent_bytes (0 = default 256 MiB) with read_threads
  * (0 = default) positional reads each, the read of one piece overlapping the engine's work on the previous one.
  * blocks_out (may be NULL) receives up to blocks_cap entries, one per 32 KiB block.  report_out (may be NULL)
  * receives 5 values: file bytes, physical records, records with a checksum mismatch, first 32 KiB block holding

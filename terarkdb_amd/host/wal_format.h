@@ -98,7 +98,7 @@ struct VerifiedLogImage {
 Status VerifyLogImage(RecordVerifier* verifier, const char* img, size_t n, uint64_t log_number, VerifiedLogImage* out);
 
 struct LogFileScanOptions {
-  size_t extent_bytes = 64u << 20;  // the file is read and submitted in pieces of this size
+  size_t extent_bytes = 256u << 20;  // the file is read and submitted in pieces of this size
   int read_threads = 8;             // positional reads that fill one piece
 };
 // Reads a whole log file and checks it, the way recovery meets it (db/log_reader.cc:276-312 reads it block by

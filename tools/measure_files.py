@@ -80,6 +80,33 @@ def main():
     res["file_checksum"] = {"bytes": size.value, "runs": runs,
                             "cpu_port_read_plus_crc_GBps": round(size.value / (time.perf_counter() - t0) / 1e9, 2)}
 
+    # a log file the way recovery meets it: the db_bench-shaped log (2040-byte records), file -> per-block verdicts
+    n_rec = int(os.environ.get("MF_LOG_RECORDS", "1000000"))
+    OL = O.lib()
+    t = O.OracleLog(recycle=False, log_number=7, hw=True)
+    OL.oracle_wal_write_dbbench_records(t.writer, n_rec, 301)
+    log_size = t.written_bytes()
+    covered = OL.oracle_wal_writer_crc_bytes(t.writer)
+    log_path = os.path.join(tmp, "000007.log")
+    np.frombuffer((C.c_uint8 * log_size).from_address(OL.oracle_sink_data(t.sink)), dtype=np.uint8).tofile(log_path)
+    t.close()
+    runs = []
+    report = (C.c_uint64 * 5)()
+    for label, extent in (("one piece (read, then verify)", 1 << 40), ("16 MiB pieces", 16 << 20),
+                          ("64 MiB pieces", 64 << 20), ("256 MiB pieces", 256 << 20)):
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            rc = capi.lib.tcrc_shim_wal_verify_file(eng.ctx, log_path.encode(), 7, extent, 8, None, 0, report, m, 256)
+            dt = time.perf_counter() - t0
+            assert rc == 0 and report[0] == log_size and report[2] == 0, (rc, m.value, list(report))
+            best = dt if best is None else min(best, dt)
+        runs.append({"pieces": label, "seconds": round(best, 4), "file_GBps": round(log_size / best / 1e9, 2)})
+        print("log_file", runs[-1], flush=True)
+    res["log_file_verify"] = {"bytes": log_size, "covered_bytes": covered, "physical_records": int(report[1]),
+                              "read_threads": 8, "runs": runs}
+    os.remove(log_path)
+
     # the command-line tool
     tcrc = os.path.join(ROOT, "terarkdb_amd", "bin", "tcrc")
     p = subprocess.run([tcrc, "crc32c", "--block_size=4096"], capture_output=True, text=True, timeout=300)
