@@ -121,10 +121,40 @@ int check_descs(const tcrc_desc* d, uint64_t n, uint64_t base_bytes, uint64_t af
   return TCRC_OK;
 }
 
+int check_flags_host(uint32_t flags, uint32_t allowed) {
+  if (flags & ~allowed) return fail(TCRC_ERR_INVALID, "unknown or misplaced flag bits");
+  return TCRC_OK;
+}
+
 // Small batches are served without copy commands when the input is short enough to bounce through the
 // zero-copy block or already lies in pinned memory.
 bool zero_copy_fits(const void* h_base, uint64_t base_bytes, uint64_t n) {
   return n <= tcrc_ctx::kZcMaxItems && base_bytes <= kZcMaxInput && (base_bytes <= tcrc_ctx::kZcData || is_pinned(h_base));
+}
+
+// A small batch gives every buffer one wave; a buffer of hundreds of KiB would keep that wave busy for
+// hundreds of microseconds.  Such batches (a table's filter or index block among its meta blocks) go
+// through the long-buffer path instead, which spreads every buffer over the chip.
+constexpr uint32_t kLongRouteLen = 80u << 10;  // measured break-even with one wave per buffer: about 64 KiB
+bool wants_long_route(const tcrc_desc* d, uint64_t n, const uint8_t* h_suffix) {
+  if (h_suffix || n > tcrc_ctx::kZcMaxItems) return false;
+  for (uint64_t i = 0; i < n; ++i)
+    if (d[i].len >= kLongRouteLen) return true;
+  return false;
+}
+
+int upload(tcrc_ctx* ctx, tcrc_scratch* s, const void* h, size_t bytes, size_t slack);
+
+// Plain CRCs of the descriptors' spans through the long-buffer path, into h_crc.  Caller holds host_mu.
+int long_route(tcrc_ctx* ctx, const void* h_base, uint64_t base_bytes, const tcrc_desc* h_desc, uint64_t n,
+               uint32_t* h_crc) {
+  if (int rc = upload(ctx, &ctx->host_data, h_base, base_bytes, 64)) return rc;
+  if (int rc = scratch_reserve(ctx, &ctx->host_out, n * 4)) return rc;
+  if (int rc = tcrc_dev_extend_long(ctx, ctx->host_data.p, h_desc, n, 0, (uint32_t*)ctx->host_out.p, ctx->host_stream))
+    return rc;
+  HIP_TRY(hipMemcpyAsync(h_crc, ctx->host_out.p, n * 4, hipMemcpyDeviceToHost, ctx->host_stream));
+  HIP_TRY(hipStreamSynchronize(ctx->host_stream));
+  return TCRC_OK;
 }
 
 int upload(tcrc_ctx* ctx, tcrc_scratch* s, const void* h, size_t bytes, size_t slack = 64) {
@@ -204,6 +234,13 @@ int tcrc_host_batch_stamp(tcrc_ctx* ctx, const void* h_base, uint64_t base_bytes
   std::lock_guard<std::mutex> lock(ctx->host_mu);
   TCRC_DEVICE_SCOPE(ctx);
   if (int rc = host_begin(ctx)) return rc;
+  if (wants_long_route(h_desc, n, h_suffix)) {
+    if (int rc = check_flags_host(flags, TCRC_F_MASK)) return rc;
+    if (int rc = long_route(ctx, h_base, base_bytes, h_desc, n, h_out)) return rc;
+    if (flags & TCRC_F_MASK)
+      for (uint64_t i = 0; i < n; ++i) h_out[i] = tcrc_mask(h_out[i]);
+    return TCRC_OK;
+  }
   if (zero_copy_fits(h_base, base_bytes, n)) {
     // Small batch: no copies.  The kernel reads the bytes where they are (pinned memory) or from the bounce
     // area, takes its descriptors from the zero-copy block and writes the results there.
@@ -275,6 +312,30 @@ int tcrc_host_batch_verify(tcrc_ctx* ctx, const void* h_base, uint64_t base_byte
   std::lock_guard<std::mutex> lock(ctx->host_mu);
   TCRC_DEVICE_SCOPE(ctx);
   if (int rc = host_begin(ctx)) return rc;
+  if (wants_long_route(h_desc, n, h_suffix)) {
+    if (int rc = check_flags_host(flags, TCRC_F_MASK | TCRC_F_EXPECT_AFTER | TCRC_F_EXPECT_BEFORE)) return rc;
+    if (!h_expected && !(flags & (TCRC_F_EXPECT_AFTER | TCRC_F_EXPECT_BEFORE)))
+      return fail(TCRC_ERR_INVALID, "verify needs h_expected or an in-image expectation flag");
+    std::vector<uint32_t> crc(n);
+    if (int rc = long_route(ctx, h_base, base_bytes, h_desc, n, crc.data())) return rc;
+    for (uint64_t i = 0; i < n; ++i) {
+      const uint32_t masked = tcrc_mask(crc[i]);
+      uint32_t stored;
+      if (h_expected) {
+        stored = h_expected[i];
+      } else {
+        const uint8_t* e = (const uint8_t*)h_base + h_desc[i].offset;
+        e = (flags & TCRC_F_EXPECT_AFTER) ? e + h_desc[i].len : e - 6;
+        stored = (uint32_t)e[0] | ((uint32_t)e[1] << 8) | ((uint32_t)e[2] << 16) | ((uint32_t)e[3] << 24);
+      }
+      const bool good = stored == masked;
+      if (h_out) h_out[i] = masked;
+      if (h_ok) h_ok[i] = good ? 1 : 0;
+      if (!good && h_counts[TCRC_CNT_MISMATCH]++ == 0) h_counts[TCRC_CNT_FIRST_BAD] = i;
+    }
+    h_counts[TCRC_CNT_CHECKED] = n;
+    return TCRC_OK;
+  }
   if (zero_copy_fits(h_base, base_bytes, n)) {
     // Small batch (one block fetched by a read, a handful of meta blocks): no copy commands.  The kernel
     // reads the bytes where they lie or from the bounce area and leaves values and verdicts in the

@@ -5,6 +5,7 @@
 namespace terarkdb_amd {
 
 namespace {
+const uint64_t kMaxBlockBytes = 1ull << 30;  // contents + type byte must fit one engine span
 Status EngineError() { return Status::IOError(std::string("checksum engine: ") + tcrc_last_error()); }
 }  // namespace
 
@@ -25,7 +26,7 @@ Status ComputeBlockTrailers(tcrc_ctx* ctx, const std::vector<Slice>& contents, c
   std::vector<tcrc_desc> spans(n);
   size_t pos = 0;
   for (size_t i = 0; i < n; ++i) {
-    if (contents[i].size() >= 0xffffffffull) {
+    if (contents[i].size() >= kMaxBlockBytes) {  // the engine walks spans of up to 1 GiB
       tcrc_host_free(ctx, stage);
       return Status::InvalidArgument("block too large");
     }
@@ -73,8 +74,11 @@ Status CheckBlockChecksums(tcrc_ctx* ctx, const Slice& image, uint64_t image_fil
   std::vector<tcrc_desc> spans(n);
   for (size_t i = 0; i < n; ++i) {
     const BlockHandle& h = handles[i];
-    if (h.offset < image_file_offset || h.offset - image_file_offset + h.size + kBlockTrailerSize > image.size())
+    const uint64_t rel = h.offset - image_file_offset;  // checked without letting offset + size wrap around
+    if (h.offset < image_file_offset || rel > image.size() || h.size > image.size() - rel ||
+        kBlockTrailerSize > image.size() - rel - h.size)
       return Status::InvalidArgument("block handle outside the image");
+    if (h.size >= kMaxBlockBytes) return Status::InvalidArgument("block too large");
     spans[i].offset = h.offset - image_file_offset;
     spans[i].len = static_cast<uint32_t>(h.size + 1);  // contents and type byte (fetcher :48)
     spans[i].init = 0;

@@ -86,6 +86,9 @@ Status BoundsStatus(const BlockHandle& h, uint64_t file_size, const std::string&
                             std::to_string(avail));
 }
 
+// contents + type byte must fit one engine span
+const uint64_t kMaxBlockBytes = 1ull << 30;
+
 // One block on the verification list.
 struct Item {
   BlockHandle handle;
@@ -121,8 +124,8 @@ Status CheckPacked(const Run& r, std::vector<Item>* items, std::vector<std::stri
     Item& it = (*items)[i];
     it.status = BoundsStatus(it.handle, r.file_size, r.file_name);
     if (!it.status.ok()) continue;
-    if (it.handle.size + 1 >= 0xffffffffull) {
-      it.status = Status::NotSupported("block of 4 GiB or more");
+    if (it.handle.size >= kMaxBlockBytes) {
+      it.status = Status::NotSupported("block of 1 GiB or more");
       continue;
     }
     const size_t want = static_cast<size_t>(it.handle.size) + kBlockTrailerSize;
@@ -186,8 +189,8 @@ Status CheckExtents(const Run& r, std::vector<Item>* items) {
   for (size_t i = 0; i < n;) {
     Item& first = (*items)[i];
     first.status = BoundsStatus(first.handle, r.file_size, r.file_name);
-    if (first.status.ok() && first.handle.size + 1 >= 0xffffffffull)
-      first.status = Status::NotSupported("block of 4 GiB or more");
+    if (first.status.ok() && first.handle.size >= kMaxBlockBytes)
+      first.status = Status::NotSupported("block of 1 GiB or more");
     if (!first.status.ok()) {  // cannot be read at all: reported in order later
       ++i;
       continue;
@@ -200,8 +203,8 @@ Status CheckExtents(const Run& r, std::vector<Item>* items) {
       Item& it = (*items)[j];
       if (j > i) {
         it.status = BoundsStatus(it.handle, r.file_size, r.file_name);
-        if (it.status.ok() && it.handle.size + 1 >= 0xffffffffull)
-          it.status = Status::NotSupported("block of 4 GiB or more");
+        if (it.status.ok() && it.handle.size >= kMaxBlockBytes)
+          it.status = Status::NotSupported("block of 1 GiB or more");
         if (!it.status.ok()) continue;  // does not break the run
         const uint64_t end = it.handle.offset + it.handle.size + kBlockTrailerSize;
         if (it.handle.offset < e.lo || std::max(end, hi) - e.lo > r.options.extent_bytes) break;

@@ -34,6 +34,7 @@ void Writer::Reserve(size_t more) {
   size_t cap = stage_cap_ ? stage_cap_ : (size_t)1 << 20;
   while (cap < stage_size_ + more) cap *= 4;
   char* fresh = stamper_->AllocStaging(cap);
+  if (!fresh) abort();  // out of memory: like the reference's buffers, nothing sensible to continue with
   if (stage_size_) memcpy(fresh, stage_, stage_size_);
   if (stage_) stamper_->FreeStaging(stage_);
   stage_ = fresh;

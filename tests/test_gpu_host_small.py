@@ -166,3 +166,51 @@ def test_descriptor_limits(eng):
     assert counts.cpu().tolist() == [1, 1, 3]
     got = out.cpu().numpy().view(np.uint32)
     assert got[0] == want[0] and got[2] == want[1]
+
+
+def test_few_buffers_some_of_them_long(eng):
+    """A small batch that holds long buffers (a table's filter or index block among its meta blocks) takes
+    another route through the engine; values, verdicts and counters must not depend on it."""
+    import terarkdb_amd.capi as capi
+    L = capi.lib
+    rng = np.random.default_rng(21)
+    lens = [300000, 0, 17, (1 << 20) + 3, 4097, 81920, 81919]
+    total = sum(lens) + 5 * len(lens) + 64
+    img = O.splitmix(total + 8 - total % 8, 77)[:total].copy()
+    offs, pos = [], 13
+    for ln in lens:
+        offs.append(pos)
+        pos += ln + 5
+    inits = rng.integers(0, 2**32, len(lens), dtype=np.uint64).astype(np.uint32)
+    d = _descs(offs, lens, inits)
+    n = len(lens)
+    for masked in (False, True):
+        want = O.batch_extend(img, np.array(offs, dtype=np.uint64), np.array(lens, dtype=np.uint32), inits, None, masked)
+        out = (C.c_uint32 * n)()
+        assert L.tcrc_host_batch_stamp(eng.ctx, img.ctypes.data, total, d, n, None, capi.F_MASK if masked else 0, out) == 0
+        assert (np.frombuffer(out, dtype=np.uint32) == want).all()
+    # trailers in the image: [span][stored masked value]
+    d0 = _descs(offs, lens, [0] * n)
+    want = O.batch_extend(img, np.array(offs, dtype=np.uint64), np.array(lens, dtype=np.uint32), None, None, True)
+    for o, ln, w in zip(offs, lens, want):
+        img[o + ln:o + ln + 4] = np.frombuffer(int(w).to_bytes(4, "little"), dtype=np.uint8)
+    counts = (C.c_uint64 * 3)()
+    ok = np.full(n, 9, dtype=np.uint8)
+    got = np.zeros(n, dtype=np.uint32)
+    args = (eng.ctx, img.ctypes.data, total, d0, n, None, capi.F_EXPECT_AFTER, None, got.ctypes.data, ok.ctypes.data, counts)
+    assert L.tcrc_host_batch_verify(*args) == 0
+    assert list(counts) == [0, 2**64 - 1, n] and ok.tolist() == [1] * n and (got == want).all()
+    img[offs[3] + 999999] ^= 1   # inside the 1 MiB buffer
+    img[offs[5] + lens[5] + 2] ^= 4  # a stored value
+    assert L.tcrc_host_batch_verify(*args) == 0
+    assert list(counts) == [2, 3, n] and ok.tolist() == [1, 1, 1, 0, 1, 0, 1]
+    # given values instead of in-image ones; unknown flag bits are refused on this route too
+    expected = want.copy()
+    expected[0] ^= 1
+    assert L.tcrc_host_batch_verify(eng.ctx, img.ctypes.data, total, d0, n, None, 0, expected.ctypes.data, None, None,
+                                    counts) == 0
+    assert list(counts) == [2, 0, n]
+    assert L.tcrc_host_batch_verify(eng.ctx, img.ctypes.data, total, d0, n, None, capi.F_STORE_AFTER,
+                                    expected.ctypes.data, None, None, counts) == capi.ERR_INVALID
+    assert L.tcrc_host_batch_verify(eng.ctx, img.ctypes.data, total, d0, n, None, 0, None, None, None,
+                                    counts) == capi.ERR_INVALID
