@@ -56,6 +56,28 @@ def test_dump_wal(tmp_path):
     assert out == W.HEADER + "\n" + "".join(b.row(off, False) for b, (_, off) in zip(batches, recs))
 
 
+def test_verify_wal(tmp_path):
+    clean = tmp_path / "000123.log"
+    img = O.build_wal_image(0, n_random=200)
+    clean.write_bytes(img)
+    want = O.wal_scan_blocks(img, 123)
+    damaged = bytearray(img)
+    recs, n = O.list_physical(img, 123)
+    off, typ, ln, _ = (int(x) for x in recs[n // 2])
+    damaged[off + 7 + ln // 2] ^= 0x80
+    torn = tmp_path / "000124.log"
+    torn.write_bytes(bytes(damaged[:-3]))  # a flipped bit in the middle and a record cut short at the end
+    rc, out, err = run("verify_wal", str(clean), str(torn))
+    assert rc == 1, err
+    lines = out.splitlines()
+    assert lines[0] == "%s: %d bytes, %d physical records, 0 with a checksum mismatch" % (clean, len(img), int(want[:, 0].sum()))
+    assert lines[1].startswith("%s: %d bytes, " % (torn, len(img) - 3))
+    assert "1 with a checksum mismatch (first in 32 KiB block %d)" % (off // 32768) in lines[1]
+    assert lines[1].endswith(", torn record at the end of the file")
+    rc, out, err = run("verify_wal", str(tmp_path / "missing.log"))
+    assert rc == 1 and "IO error" in err
+
+
 def _make_db_dir(tmp_path):
     """A directory shaped like a database: table files, write-ahead logs, a MANIFEST, other files."""
     import shutil
