@@ -120,6 +120,18 @@ int tcrc_shim_dump_wal(tcrc_ctx* ctx, const char* path, int print_header, int pr
 int tcrc_shim_dump_wal_cb(tcrc_shim_scan_fn fn, void* user, const char* path, int print_header, int print_values,
                           char* out, size_t out_cap, size_t* out_len, char* err, size_t err_cap, size_t* err_len);
 
+/* Records of the persistent block cache (utilities/persistent_cache/block_cache_tier_file.cc:55-192):
+ * serialize writes n records [magic | crc | key size | value size | key | value] for the keys and values at
+ * base + key_off[i] / val_off[i] into out (out_cap bytes; *out_len receives the size, also when out is too
+ * small or NULL), the crc32c of all records computed in one engine submission (CacheRecord::ComputeCRC,
+ * :108-118).  check gives ok_out[i] = what CacheRecord::Deserialize returns (:162-192) for the record of
+ * sizes[i] bytes at image + offs[i].  Return 0, -1 on errors, -3 (serialize) when out_cap is too small. */
+int tcrc_shim_cache_records_serialize(tcrc_ctx* ctx, const void* base, const uint64_t* key_off, const uint32_t* key_len,
+                                      const uint64_t* val_off, const uint32_t* val_len, size_t n, void* out,
+                                      size_t out_cap, size_t* out_len);
+int tcrc_shim_cache_records_check(tcrc_ctx* ctx, const void* image, size_t image_bytes, const uint64_t* offs,
+                                  const uint32_t* sizes, size_t n, uint8_t* ok_out);
+
 /* Checks every physical record of one log file the way recovery's reader meets it (db/log_reader.cc:276-406
  * with checksum = true): the file is read in pieces of extent_bytes (0 = default 256 MiB) with read_threads
  * (0 = default) positional reads each, the read of one piece overlapping the engine's work on the previous one.

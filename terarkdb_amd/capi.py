@@ -123,6 +123,8 @@ SIGNATURES.update({
                                    C.POINTER(_sz)]),
     "tcrc_shim_footer_encode": (_i, [_i, _u32, _i, _u64, _u64, _u64, _u64, _vp]),
     "tcrc_shim_footer_decode": (_i, [_vp, _sz, C.POINTER(_i), C.POINTER(_u32), C.POINTER(_u64), _vp, C.c_char_p, _sz]),
+    "tcrc_shim_cache_records_serialize": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _sz, C.POINTER(_sz)]),
+    "tcrc_shim_cache_records_check": (_i, [_vp, _vp, _sz, _vp, _vp, _sz, _vp]),
     "tcrc_shim_wal_verify_file": (_i, [_vp, C.c_char_p, _u64, _sz, _i, _vp, _sz, _vp, C.c_char_p, _sz]),
     "tcrc_shim_verify_db": (_i, [_vp, C.c_char_p, _u32, _u32, C.POINTER(_u64), C.c_char_p, _sz, C.c_char_p, _sz]),
     "tcrc_shim_file_checksum": (_i, [_vp, C.c_char_p, _u64, _sz, C.POINTER(_u32), C.POINTER(_u64), C.c_char_p, _sz]),

@@ -11,6 +11,7 @@
 
 #include "../../include/tcrc_shim.h"
 #include "block_trailer.h"
+#include "cache_record.h"
 #include "db_verify.h"
 #include "file_checksum.h"
 #include "sst_verify.h"
@@ -417,6 +418,35 @@ int tcrc_shim_footer_decode(const void* tail, size_t n, int* checksum, uint32_t*
   }
   if (message && message_cap) snprintf(message, message_cap, "%s", s.ToString().c_str());
   return s.ok() ? 0 : -1;
+}
+
+int tcrc_shim_cache_records_serialize(tcrc_ctx* ctx, const void* base, const uint64_t* key_off, const uint32_t* key_len,
+                                      const uint64_t* val_off, const uint32_t* val_len, size_t n, void* out,
+                                      size_t out_cap, size_t* out_len) {
+  std::vector<Slice> keys(n), vals(n);
+  const char* b = static_cast<const char*>(base);
+  for (size_t i = 0; i < n; ++i) {
+    keys[i] = Slice(b + key_off[i], key_len[i]);
+    vals[i] = Slice(b + val_off[i], val_len[i]);
+  }
+  std::string bytes;
+  Status s = SerializeCacheRecords(ctx, keys, vals, &bytes);
+  if (!s.ok()) return -1;
+  if (out_len) *out_len = bytes.size();
+  if (!out || out_cap < bytes.size()) return -3;
+  memcpy(out, bytes.data(), bytes.size());
+  return 0;
+}
+
+int tcrc_shim_cache_records_check(tcrc_ctx* ctx, const void* image, size_t image_bytes, const uint64_t* offs,
+                                  const uint32_t* sizes, size_t n, uint8_t* ok_out) {
+  std::vector<std::pair<uint64_t, uint32_t>> lbas(n);
+  for (size_t i = 0; i < n; ++i) lbas[i] = std::make_pair(offs[i], sizes[i]);
+  std::vector<CacheRecordView> views;
+  Status s = DeserializeCacheRecords(ctx, Slice(static_cast<const char*>(image), image_bytes), lbas, &views);
+  if (!s.ok()) return -1;
+  for (size_t i = 0; i < n; ++i) ok_out[i] = views[i].ok ? 1 : 0;
+  return 0;
 }
 
 int tcrc_shim_wal_verify_file(tcrc_ctx* ctx, const char* path, uint64_t log_number, size_t extent_bytes,
