@@ -187,6 +187,9 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p) {
       const uint32_t other = __shfl_xor(Rmax, o);
       Rmax = other > Rmax ? other : Rmax;
     }
+    // the same in every lane now: kept in a scalar register, so that the row loops and the row classes
+    // below cost scalar instructions
+    Rmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)Rmax);
     // A buffer with fewer rows than the longest of its wave starts later, so that all end together.
     // message offset of this lane's column in row r is m0 + r*D
     const int m0 = 16 * j - (int)a0 - (int)((Rmax - R) * D);
@@ -294,6 +297,7 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p) {
         const uint32_t other = __shfl_xor(fmax, o);
         fmax = other > fmax ? other : fmax;
       }
+      fmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)fmax);
       const uint32_t head_end = fmax + 1u < Rmax ? fmax + 1u : Rmax;
       const uint32_t tail_begin = Rmax - 1u > head_end ? Rmax - 1u : head_end;
       // Every burst issues its (up to) four row loads together - a load is skipped by lanes whose column
@@ -301,16 +305,25 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p) {
       for (; r < Rmax; r += 4u) {
         const uint32_t cnt = Rmax - r;  // rows in this burst if fewer than four
         const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-        const uint4 a = load_checked(r);
-        const uint4 b = cnt > 1u ? load_checked(r + 1u) : z;
-        const uint4 c = cnt > 2u ? load_checked(r + 2u) : z;
-        const uint4 d = cnt > 3u ? load_checked(r + 3u) : z;
         if (r >= head_end && r + 4u <= tail_begin) {
+          // four rows that are whole for every buffer of the wave that is walked at all: no per-row checks
+          uint4 a = z, b = z, c = z, d = z;
+          if (live) {
+            const uint8_t* q = ptr + (m0 + (int)(r * D));
+            a = load16<NT>(q);
+            b = load16<NT>(q + D);
+            c = load16<NT>(q + 2 * D);
+            d = load16<NT>(q + 3 * D);
+          }
           fold_plain(a);
           fold_plain(b);
           fold_plain(c);
           fold_plain(d);
         } else {
+          const uint4 a = load_checked(r);
+          const uint4 b = cnt > 1u ? load_checked(r + 1u) : z;
+          const uint4 c = cnt > 2u ? load_checked(r + 2u) : z;
+          const uint4 d = cnt > 3u ? load_checked(r + 3u) : z;
           if (r >= head_end && r < tail_begin) fold_plain(a); else fold_checked(a, r);
           if (cnt > 1u) {
             if (r + 1u >= head_end && r + 1u < tail_begin) fold_plain(b); else fold_checked(b, r + 1u);
