@@ -203,10 +203,10 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p) {
     };
     // A column that may stick out of the message at either end or hold some of its first four
     // bytes (which carry the initial register): loaded only if it overlaps the message ...
-    auto load_checked = [&](uint32_t r) -> uint4 {
+    auto load_checked = [&](uint32_t r, bool keep) -> uint4 {
       const int m = m0 + (int)(r * D);
       uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (live && m > -16 && m < (int)elen) v = load16<NT>(ptr + m);
+      if (live && m > -16 && m < (int)elen) v = (NT && !keep) ? load16<true>(ptr + m) : load16<false>(ptr + m);
       return v;
     };
     // ... and trimmed to the message, with the initial register folded into message bytes 0..3.
@@ -320,10 +320,14 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p) {
           fold_plain(c);
           fold_plain(d);
         } else {
-          const uint4 a = load_checked(r);
-          const uint4 b = cnt > 1u ? load_checked(r + 1u) : z;
-          const uint4 c = cnt > 2u ? load_checked(r + 2u) : z;
-          const uint4 d = cnt > 3u ? load_checked(r + 3u) : z;
+          // When the trailer is stored into the image behind the buffer, the burst that holds the last row
+          // is loaded with the default cache policy: the line the store goes to is then still in the cache,
+          // and the store does not have to fetch it again.
+          const bool keep = (p.flags & TCRC_F_STORE_AFTER) && r + 4u >= Rmax;
+          const uint4 a = load_checked(r, keep);
+          const uint4 b = cnt > 1u ? load_checked(r + 1u, keep) : z;
+          const uint4 c = cnt > 2u ? load_checked(r + 2u, keep) : z;
+          const uint4 d = cnt > 3u ? load_checked(r + 3u, keep) : z;
           if (r >= head_end && r < tail_begin) fold_plain(a); else fold_checked(a, r);
           if (cnt > 1u) {
             if (r + 1u >= head_end && r + 1u < tail_begin) fold_plain(b); else fold_checked(b, r + 1u);
