@@ -145,7 +145,8 @@ int tcrc_shim_wal_verify_file(tcrc_ctx* ctx, const char* path, uint64_t log_numb
 /* File-level DBImpl::VerifyChecksum (db/db_impl.cc:4657-4690) over a database directory: every NNNNNN.sst in
  * file-number order (stopping at the first corrupt one, whose name goes to bad_file and whose status to
  * message), then a checksum scan of NNNNNN.log and MANIFEST-NNNNNN.  Files are dealt to shard_index of
- * shard_count by position (one shard per GPU).  report_out (may be NULL) receives 8 values: table files
+ * shard_count by size, largest first to the shard with the fewest bytes so far (one shard per GPU; every
+ * caller computes the same deal from the same listing).  report_out (may be NULL) receives 8 values: table files
  * verified, table files declined, table blocks, table bytes covered, log files, log bytes, log records, log
  * records with a checksum mismatch.  Returns 0 OK, 1 Corruption, -1 other errors. */
 int tcrc_shim_verify_db(tcrc_ctx* ctx, const char* dir, uint32_t shard_index, uint32_t shard_count, uint64_t* report_out,

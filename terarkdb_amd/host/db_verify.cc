@@ -4,6 +4,7 @@
 #include <errno.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 
 #include <algorithm>
 #include <memory>
@@ -17,8 +18,36 @@ namespace {
 struct Named {
   uint64_t number;
   std::string path;
+  uint64_t bytes = 0;
   bool operator<(const Named& o) const { return number != o.number ? number < o.number : path < o.path; }
 };
+
+// Deals files to shards so that the shards' byte totals come out even: largest file first, each to the
+// shard that has the least so far (ties: the lower shard).  Every rank computes the same deal from the
+// same directory listing.  files must be sorted; returns this shard's files, still sorted.
+std::vector<Named> DealBySize(const std::vector<Named>& files, uint32_t shard_index, uint32_t shard_count) {
+  std::vector<size_t> order(files.size());
+  for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return files[a].bytes > files[b].bytes; });
+  std::vector<uint64_t> load(shard_count, 0);
+  std::vector<char> mine(files.size(), 0);
+  for (size_t k : order) {
+    uint32_t best = 0;
+    for (uint32_t s = 1; s < shard_count; ++s)
+      if (load[s] < load[best]) best = s;
+    load[best] += files[k].bytes + 1;  // empty files still take turns
+    if (best == shard_index) mine[k] = 1;
+  }
+  std::vector<Named> out;
+  for (size_t i = 0; i < files.size(); ++i)
+    if (mine[i]) out.push_back(files[i]);
+  return out;
+}
+
+uint64_t FileBytes(const std::string& path) {
+  struct stat st;
+  return stat(path.c_str(), &st) == 0 ? static_cast<uint64_t>(st.st_size) : 0;
+}
 
 // NNNNNN<suffix> -> number (util/filename.cc:306-343); false for other names
 bool NumberedName(const std::string& name, const char* suffix, uint64_t* number) {
@@ -94,25 +123,26 @@ Status VerifyDbDirectory(tcrc_ctx* ctx, const std::string& dir, uint32_t shard_i
     const std::string name = e->d_name;
     uint64_t num = 0;
     if (NumberedName(name, ".sst", &num) || NumberedName(name, ".ldb", &num)) {
-      tables.push_back(Named{num, dir + "/" + name});
+      tables.push_back(Named{num, dir + "/" + name, 0});
     } else if (NumberedName(name, ".log", &num)) {
-      logs.push_back(Named{num, dir + "/" + name});
+      logs.push_back(Named{num, dir + "/" + name, 0});
     } else if (name.compare(0, 9, "MANIFEST-") == 0 && NumberedName(name.substr(9), "", &num)) {
-      logs.push_back(Named{num, dir + "/" + name});
+      logs.push_back(Named{num, dir + "/" + name, 0});
     }
   }
   closedir(d);
   std::sort(tables.begin(), tables.end());
   std::sort(logs.begin(), logs.end());
+  for (Named& t : tables) t.bytes = FileBytes(t.path);
+  for (Named& l : logs) l.bytes = FileBytes(l.path);
   std::vector<std::string> files;
-  for (const Named& t : tables) files.push_back(t.path);
-  Status s = VerifyTableFiles(ctx, files, shard_index, shard_count, report, options);
+  for (const Named& t : DealBySize(tables, shard_index, shard_count)) files.push_back(t.path);
+  Status s = VerifyTableFiles(ctx, files, 0, 1, report, options);
   if (!s.ok()) return s;
-  for (size_t i = 0; i < logs.size(); ++i) {
-    if (i % shard_count != shard_index) continue;
-    s = ScanLogFile(ctx, logs[i].path, report);
+  for (const Named& l : DealBySize(logs, shard_index, shard_count)) {
+    s = ScanLogFile(ctx, l.path, report);
     if (!s.ok()) {
-      report->first_bad_file = logs[i].path;
+      report->first_bad_file = l.path;
       return s;
     }
   }

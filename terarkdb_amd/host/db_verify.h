@@ -29,7 +29,9 @@ struct DbVerifyReport {
 Status VerifyTableFiles(tcrc_ctx* ctx, const std::vector<std::string>& files, uint32_t shard_index, uint32_t shard_count,
                         DbVerifyReport* report, const SstVerifyOptions& options = SstVerifyOptions());
 
-// All table files of `dir` in file-number order, then its logs and MANIFEST files.  A bad log record is
+// All table files of `dir` in file-number order, then its logs and MANIFEST files.  With several shards the
+// files are dealt by size (largest first, to the shard with the fewest bytes so far), so that the shards of a
+// directory with files of very different sizes finish together; every shard computes the same deal.  A bad log record is
 // not an error of the call (recovery policy decides what it means): it is counted and noted.
 Status VerifyDbDirectory(tcrc_ctx* ctx, const std::string& dir, uint32_t shard_index, uint32_t shard_count,
                          DbVerifyReport* report, const SstVerifyOptions& options = SstVerifyOptions());

@@ -3,7 +3,8 @@
     python -m terarkdb_amd.verify_db DIR                                   # one GPU
     python -m torch.distributed.run --nproc-per-node N -m terarkdb_amd.verify_db DIR
 
-One process per GPU; the table, log and MANIFEST files are dealt to the ranks by position, every rank
+One process per GPU; the table, log and MANIFEST files are dealt to the ranks by size (largest
+first, to the rank with the fewest bytes so far), every rank
 verifies its share (DBImpl::VerifyChecksum's loop, db/db_impl.cc:4657-4690), and the ranks exchange their
 eight counters and their first error with one all-gather each (RCCL).  Rank 0 prints the totals and exits
 with 1 if any table file is corrupt or any log record fails its checksum.

@@ -128,6 +128,14 @@ def test_verify_db_directory(tmp_path):
     r0, r1 = verify(0, 2), verify(1, 2)
     assert r0[0] == 0 and r1[0] == 0
     assert [a + b for a, b in zip(r0[1], r1[1])] == rep
+    # files are dealt by size: no shard carries more than one (largest) file's worth above another
+    for shards in (2, 3):
+        parts = [verify(k, shards) for k in range(shards)]
+        assert all(p[0] == 0 for p in parts)
+        assert [sum(col) for col in zip(*[p[1] for p in parts])] == rep
+        loads = [p[1][3] + p[1][5] for p in parts]
+        largest = max(os.path.getsize(os.path.join(str(d), f)) for f in os.listdir(str(d)))
+        assert max(loads) - min(loads) <= largest
     # a corrupt table stops the run with the reference's status; a bad log record is counted
     off, size = lays[2].handle("data7")
     S.flip(lays[2].path, off + 3, 1)
