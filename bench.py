@@ -201,9 +201,9 @@ def main():
     # of the engine's device counter block; the copy to the host waits for the K launches
     totals = gather_verify_counts(counts, lambda r: r * N_BLOCKS)
     t_cnt = time.perf_counter()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
+    # That all-gather is the closing barrier: no rank gets its result before every rank has contributed its
+    # counters, which a rank's stream produces only after its K launches.  A second collective would only add
+    # its own latency to the timed region.
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if os.environ.get("BENCH_DEBUG"):
