@@ -38,7 +38,9 @@ typedef struct tcrc_ctx tcrc_ctx;
  * (longer inputs: tcrc_dev_extend_long, tcrc_extend).  The host-pointer entry points
  * reject a longer descriptor with TCRC_ERR_TOO_LARGE; the device-pointer ones cannot
  * see the descriptors, so there the kernel reads nothing for such a descriptor, its
- * output value is unspecified and a verify counts it as a mismatch. */
+ * output value is unspecified and a verify counts it as a mismatch.  Offsets in device-resident
+ * descriptors are trusted like any pointer handed to a kernel: a span outside the caller's allocation is
+ * an out-of-bounds access on the GPU. */
 typedef struct tcrc_desc {
   uint64_t offset;
   uint32_t len;
