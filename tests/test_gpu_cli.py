@@ -208,4 +208,4 @@ def test_integration_example_program(tmp_path):
     exe = os.path.join(ROOT, "terarkdb_amd", "bin", "integration_example")
     p = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=120)
     assert p.returncode == 0, p.stdout + p.stderr
-    assert "integration example ok" in p.stdout and "verdicts from one device pass" in p.stdout
+    assert "integration example ok" in p.stdout and "verdicts from the engine" in p.stdout
