@@ -1,0 +1,21 @@
+"""Synthetic corpora generated directly in device memory (benchmarks and tests)."""
+
+
+def splitmix_dev(nbytes, state=301):
+    """The splitmix64 byte stream the benchmark configurations are defined on: state `state`, the golden
+    gamma 0x9e3779b97f4a7c15 added before each 8-byte little-endian word, mixers 0xbf58476d1ce4e5b9 and
+    0x94d049bb133111eb with shifts 30 / 27 / 31.  Returns a uint8 tensor on the current GPU."""
+    import torch
+    assert nbytes % 8 == 0
+    n = nbytes // 8
+    idx = torch.arange(1, n + 1, dtype=torch.int64, device="cuda")
+    golden = -7046029254386353131  # 0x9e3779b97f4a7c15 as int64
+    z = idx * golden + state
+
+    def lsr(x, k):  # logical shift right on int64
+        return (x >> k) & ((1 << (64 - k)) - 1)
+
+    z = (z ^ lsr(z, 30)) * -4658895280553007687  # 0xbf58476d1ce4e5b9
+    z = (z ^ lsr(z, 27)) * -7723592293110705685  # 0x94d049bb133111eb
+    z = z ^ lsr(z, 31)
+    return z.view(torch.uint8)

@@ -29,19 +29,8 @@ def to_dev(a):
 
 def splitmix_dev(nbytes, state=301):
     """The splitmix64 stream generated directly on the GPU (same bytes as oracle_lib.splitmix)."""
-    assert nbytes % 8 == 0
-    n = nbytes // 8
-    idx = torch.arange(1, n + 1, dtype=torch.int64, device="cuda")
-    golden = -7046029254386353131  # 0x9e3779b97f4a7c15 as int64
-    z = idx * golden + state
-
-    def lsr(x, k):  # logical shift right on int64
-        return (x >> k) & ((1 << (64 - k)) - 1)
-
-    z = (z ^ lsr(z, 30)) * -4658895280553007687  # 0xbf58476d1ce4e5b9
-    z = (z ^ lsr(z, 27)) * -7723592293110705685  # 0x94d049bb133111eb
-    z = z ^ lsr(z, 31)
-    return z.view(torch.uint8)
+    from terarkdb_amd.synth import splitmix_dev as gen
+    return gen(nbytes, state)
 
 
 def oracle_desc_batch(buf, offs, lens, inits, suffix=None, masked=False):
