@@ -1,6 +1,6 @@
 """File-level helpers over the engine for Python callers: thin views of the C wrappers in
 include/tcrc_shim.h (whole-file table verification, database-directory verification, WAL dump,
-whole-file crc32c).  Every function needs an Engine, i.e. a GPU."""
+log-file verification, whole-file crc32c).  Every function needs an Engine, i.e. a GPU."""
 import ctypes as C
 from dataclasses import dataclass
 
@@ -83,3 +83,32 @@ def file_checksum(engine, path, size_limit=0, buffer_size=0):
     if rc != 0:
         raise capi.TcrcError(msg.value.decode())
     return crc.value, size.value
+
+
+@dataclass
+class LogVerifyResult:
+    file_size: int
+    records: int           # physical records that pass the structural checks
+    mismatches: int        # of them, records whose checksum does not match
+    first_bad_block: int   # first 32 KiB block that holds one, -1 if none
+    torn_tail: bool        # the file ends inside a header or a record
+    blocks: object         # numpy uint32 array [n_blocks, 4]: n_records, first_bad, end_offset, end_code
+
+
+def verify_log_file(engine, path, log_number, extent_bytes=0, read_threads=0):
+    """The checksum pass recovery's reader makes over one log file (db/log_reader.cc:276-406 with checksum = true),
+    the file streamed through the engine in pieces."""
+    import os
+
+    import numpy as np
+    n_blocks = (os.path.getsize(path) + 32767) // 32768 if os.path.exists(path) else 0  # a missing file: the call reports it
+    blocks = np.zeros((max(n_blocks, 1), 4), dtype=np.uint32)
+    report = (C.c_uint64 * 5)()
+    msg = C.create_string_buffer(1024)
+    rc = capi.lib.tcrc_shim_wal_verify_file(engine.ctx, path.encode(), log_number, extent_bytes, read_threads,
+                                            blocks.ctypes.data, n_blocks, report, msg, 1024)
+    if rc != 0:
+        raise capi.TcrcError(msg.value.decode())
+    first = int(report[3])
+    return LogVerifyResult(int(report[0]), int(report[1]), int(report[2]), -1 if first == 2**64 - 1 else first,
+                           int(report[4]) in (2, 4), blocks[:n_blocks])

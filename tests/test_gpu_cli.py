@@ -176,6 +176,12 @@ def test_python_file_helpers(tmp_path):
     raw = np.fromfile(lays[0].path, dtype=np.uint8)
     assert F.file_checksum(eng, lays[0].path) == (O.value(raw), raw.size)
     assert F.file_checksum(eng, lays[0].path, size_limit=1000) == (O.value(raw[:1000]), 1000)
+    lg = F.verify_log_file(eng, str(d / "000003.log"), 3)
+    want_blocks = O.wal_scan_blocks(imgs[3], 3)
+    assert (lg.blocks == want_blocks).all() and lg.records == int(want_blocks[:, 0].sum())
+    assert (lg.file_size, lg.mismatches, lg.first_bad_block, lg.torn_tail) == (len(imgs[3]), 0, -1, False)
+    with pytest.raises(capi.TcrcError):
+        F.verify_log_file(eng, str(d / "missing.log"), 1)
     with pytest.raises(capi.TcrcError):
         F.file_checksum(eng, str(d / "missing"))
     with pytest.raises(capi.TcrcError):
