@@ -125,8 +125,9 @@ int tcrc_dev_batch_verify(tcrc_ctx* ctx, const void* d_base, const tcrc_desc* d_
 /* ---- long buffers ------------------------------------------------------------------ */
 /* d_out[i] = Extend(h_desc[i].init, d_base + h_desc[i].offset, h_desc[i].len) for buffers of
  * hundreds of KiB up to 1 GiB each: every buffer is cut into segments of segment_len bytes
- * (0 = choose; otherwise a power of two >= 256) that are checksummed in parallel and merged
- * with a GF(2) shift-and-xor.  Data is on the GPU, the (few) descriptors are on the host.
+ * (0 = choose; otherwise a power of two from 256 to 2^30) that are checksummed in parallel and merged
+ * with a GF(2) shift-and-xor - one kernel launch per call (per 2048 buffers); up to 64 descriptors travel
+ * in the kernel arguments, more are copied to the GPU first.  Data is on the GPU, the (few) descriptors are on the host.
  * Values are plain CRCs (apply tcrc_mask on the host if a masked value is wanted).
  * Stands in for crc32c::Extend on large inputs (util/crc32c.cc:1226-1228; callers such as
  * utilities/backupable/backupable_db.cc:1434-1449).  Returns with d_out complete. */

@@ -226,10 +226,11 @@ class Engine:
     def extend_long(self, base, offsets, lens, inits, out, segment_len=0, stream=None):
         """Host descriptor arrays, device data; out is a device int32/uint32 tensor of len(offsets)."""
         n = len(offsets)
-        arr = (Desc * n)()
+        arr = (Desc * max(n, 1))()
         for i in range(n):
             arr[i].offset, arr[i].len, arr[i].init = int(offsets[i]), int(lens[i]), int(inits[i])
-        check(lib.tcrc_dev_extend_long(self.ctx, _dp(base), arr, n, segment_len, _dp(out), self._stream(stream)))
+        fn = lib.tcrc_dev_extend_long
+        check(fn(self.ctx, _dp(base), arr, n, segment_len, _dp(out), self._stream(stream)))
 
     def extend(self, init, data):
         """crc32c::Extend(init, data) for host bytes (bytes, bytearray or a contiguous numpy array)."""

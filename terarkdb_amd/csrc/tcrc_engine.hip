@@ -67,17 +67,6 @@ __device__ __forceinline__ uint4 load16(const uint8_t* p) {
   return make_uint4(v.x, v.y, v.z, v.w);
 }
 
-// a * b mod P (register convention bit 31 = x^0), 32 shift-and-xor steps.
-__device__ __forceinline__ uint32_t gf2_mulmod_dev(uint32_t a, uint32_t b) {
-  uint32_t prod = 0;
-#pragma unroll 8
-  for (int i = 31; i >= 0; --i) {
-    prod ^= ((a >> i) & 1u) ? b : 0u;
-    b = (b >> 1) ^ ((b & 1u) ? 0x82f63b78u : 0u);
-  }
-  return prod;
-}
-
 // Z_D via the replicated tables; A = lds + (lane & 31).
 __device__ __forceinline__ uint32_t fold_main(const uint32_t* A, uint32_t c) {
   return A[(c & 0xffu) * 32u] ^ A[8192u + ((c >> 8) & 0xffu) * 32u] ^ A[16384u + ((c >> 16) & 0xffu) * 32u] ^
@@ -89,8 +78,30 @@ __device__ __forceinline__ uint32_t fold_aux(const uint32_t* t, uint32_t c) {
   return t[c & 0xffu] ^ t[256u + ((c >> 8) & 0xffu)] ^ t[512u + ((c >> 16) & 0xffu)] ^ t[768u + (c >> 24)];
 }
 
-template <int G, bool NT>
-__global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p) {
+template <bool SEG> struct SegArgs { typedef NoLongArgs type; };
+template <> struct SegArgs<true> { typedef LongArgs type; };
+
+// One segment's remainder enters its buffer's accumulator line: XOR, then the arrival count; whoever
+// completes the count takes the value out, leaves the line zeroed for the next launch and writes the result.
+// Device-scope atomics are performed at the memory side, past the per-XCD L2s, so they need no cache
+// write-back or invalidation (which a __threadfence() would do, for every wave, to the whole L2); all the
+// protocol needs is that a wave's XOR has been performed before its count is added, i.e. that the XOR's
+// acknowledgement has come back: a wait on the vector-memory counter.
+__device__ __forceinline__ void seg_arrive(uint32_t* line, uint32_t value, uint32_t count, uint32_t total,
+                                           uint32_t* out) {
+  (void)__hip_atomic_fetch_xor(line, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const uint32_t before = __hip_atomic_fetch_add(line + 1, count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (before + count == total) {  // every other segment's XOR was acknowledged before its count was added
+    const uint32_t r = __hip_atomic_exchange(line, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    (void)__hip_atomic_exchange(line + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *out = r;
+  }
+}
+
+// SEG: the items are segments of long buffers described by `la` (tcrc_long.hip); otherwise `la` is empty.
+template <int G, bool NT, bool SEG>
+__global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p, typename SegArgs<SEG>::type la) {
   constexpr int D = 16 * G;
   constexpr int LOG2G = Geo<G>::kLog2;
   constexpr int GPW = 64 / G;  // groups (buffers) per wave
@@ -99,11 +110,30 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p) {
   constexpr int UL = G <= 16 ? 4 : 1;
   constexpr int kAuxDwords = (1 + LOG2G) * 1024 + D * UL;  // reduction sets, then x^(-8t) * x^(32 l / UL) for t < D, l < UL
   __shared__ uint32_t lds[kMainDwords + kAuxDwords];
+  // SEG: segments before every buffer of the launch, and the descriptors that came in the kernel arguments
+  __shared__ uint32_t seg_first_lds[SEG ? kLongLdsBuffers + 1 : 1];
+  __shared__ uint4 seg_inl_lds[SEG ? kLongInline : 1];
 
   const int tid = threadIdx.x;
   if (p.n_dev && *p.n_dev == 0) return;  // an empty list (uniform over the grid): nothing to set up
   for (int i = tid; i < kMainDwords; i += kThreads) lds[i] = p.tab_main[i >> 5];
   for (int i = tid; i < kAuxDwords; i += kThreads) lds[kMainDwords + i] = p.tab_aux[i];
+  if constexpr (SEG) {
+    if (la.seg_first) {
+      for (uint32_t i = tid; i <= la.nbuf; i += kThreads) seg_first_lds[i] = la.seg_first[i] - la.first_base;
+    } else if (tid == 0) {
+      // constant indices only: the argument block stays in scalar registers
+#pragma unroll
+      for (int i = 0; i < kLongInline; ++i) {
+        if (i < (int)la.nbuf) {
+          seg_first_lds[i] = la.inl_first[i];
+          seg_inl_lds[i] = make_uint4((uint32_t)la.inl[i].offset, (uint32_t)(la.inl[i].offset >> 32), la.inl[i].len,
+                                      la.inl[i].init);
+        }
+      }
+      seg_first_lds[la.nbuf] = (uint32_t)p.n;  // all segments of the launch
+    }
+  }
   __syncthreads();
 
   const int lane = tid & 63;
@@ -122,7 +152,6 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p) {
   }
   const uint64_t nrounds = (n + GPW - 1) / GPW;
   const bool wal_items = (p.flags & kFlagWalItems) != 0;
-  const bool segments = (p.flags & kFlagSegments) != 0;
 
   // the descriptor of the next round is fetched while the current round runs
   tcrc_desc d_next = {0, 0, 0};
@@ -139,7 +168,37 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p) {
       const uint64_t nb = (round + nwaves) * GPW + grp;
       if (round + nwaves < nrounds && nb < n) d_next = p.desc[nb];
     }
-    if (valid) {
+    uint32_t seg_owner = 0, seg_after = 0, seg_total = 0;
+    if constexpr (SEG) {
+      if (valid) {
+        // buffer that owns segment `buf`: the last b with seg_first[b] <= buf
+        const uint32_t sidx = (uint32_t)buf;
+        uint32_t lo = 0, hi = la.nbuf;
+        while (hi - lo > 1u) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (seg_first_lds[mid] <= sidx) lo = mid; else hi = mid;
+        }
+        const uint32_t f0 = seg_first_lds[lo];
+        tcrc_desc bd;
+        if (la.bufs) {
+          bd = la.bufs[lo];
+        } else {
+          const uint4 w = seg_inl_lds[lo];
+          bd.offset = (uint64_t)w.x | ((uint64_t)w.y << 32);
+          bd.len = w.z;
+          bd.init = w.w;
+        }
+        seg_owner = lo;
+        seg_total = seg_first_lds[lo + 1] - f0;
+        seg_after = seg_total - 1u - (sidx - f0);  // whole segments that follow this one in its buffer
+        const uint64_t end = (uint64_t)bd.len - ((uint64_t)seg_after << la.seg_shift);
+        const uint64_t seg_len = 1ull << la.seg_shift;
+        const uint64_t start = end > seg_len ? end - seg_len : 0ull;
+        off = bd.offset + start;
+        len = (uint32_t)(end - start);
+        init = sidx == f0 ? bd.init : 0xffffffffu;  // later segments start from a zero register
+      }
+    } else if (valid) {
       if (p.desc) {
         off = dsc.offset;
         len = dsc.len;
@@ -375,7 +434,7 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p) {
       if (tpad) rfin = part;
     }
 
-    uint32_t seg_owner = 0, seg_value = 0;
+    uint32_t seg_value = 0;
     bool seg_have = false;
     if (valid && j == G - 1) {
       uint32_t reg;
@@ -391,13 +450,13 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p) {
       if (sfx >= 0) reg = aux[768u + ((reg ^ (uint32_t)sfx) & 0xffu)] ^ (reg >> 8);
       const uint32_t crc = ~reg;
       const uint32_t masked = ((crc >> 15) | (crc << 17)) + kMaskDelta;
-      if (segments) {
+      if constexpr (SEG) {
         // reg is the remainder of this segment alone; q whole segments follow it in its buffer, so it
-        // enters the buffer's remainder advanced through q * segment_len bytes.  The final inversion
-        // rides on the last segment (q == 0).
-        const uint32_t q = p.seg_after[buf];
-        const uint32_t prod = gf2_mulmod_dev(reg, p.seg_pow[q]);
-        seg_owner = p.seg_owner[buf];
+        // enters the buffer's remainder advanced through q * segment_len bytes: x^(8 S q) is the product of
+        // one entry of each level of the power table.  The final inversion rides on the last segment (q == 0).
+        const uint32_t q = seg_after;
+        uint32_t prod = gf2_mulmod_dev(reg, la.pow_lo[q & (kPowEntries - 1)]);
+        if (q >= (uint32_t)kPowEntries) prod = gf2_mulmod_dev(prod, la.pow_hi[q >> 11]);
         seg_value = q == 0 ? ~prod : prod;
         seg_have = true;
       } else {
@@ -430,19 +489,22 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p) {
         }
       }
     }
-    if (segments) {
+    if constexpr (SEG) {
       // The segments of one wave usually belong to one buffer: fold them with shuffles and touch the
-      // accumulator once.  Accumulators sit one per 128-byte line (p.out is strided by 32 words)
-      // so that different buffers do not queue on the same line.
+      // accumulator once.  Accumulators sit one per 128-byte line so that different buffers do not queue
+      // on the same line.
       const uint32_t first_owner = __shfl(seg_owner, G - 1);
-      const bool any_have = __any(seg_have);
+      const uint32_t first_total = __shfl(seg_total, G - 1);
+      const unsigned long long have = __ballot(seg_have);
       if (__all(!seg_have || seg_owner == first_owner)) {
         uint32_t v = seg_have ? seg_value : 0u;
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) v ^= __shfl_xor(v, o);
-        if (lane == 0 && any_have) atomicXor(&p.out[(uint64_t)first_owner * 32u], v);
+        if (lane == 0 && have)
+          seg_arrive(la.acc + (uint64_t)first_owner * 32u, v, (uint32_t)__popcll(have), first_total,
+                     p.out + first_owner);
       } else if (seg_have) {
-        atomicXor(&p.out[(uint64_t)seg_owner * 32u], seg_value);
+        seg_arrive(la.acc + (uint64_t)seg_owner * 32u, seg_value, 1u, seg_total, p.out + seg_owner);
       }
     }
   }
@@ -497,9 +559,9 @@ int launch_batch(tcrc_ctx* ctx, BatchParams p, hipStream_t s) {
   if (wgs > (uint64_t)ctx->cus) wgs = (uint64_t)ctx->cus;
   if (wgs == 0) wgs = 1;
   if (ctx->nontemporal)
-    hipLaunchKernelGGL((k_crc_batch<G, true>), dim3((unsigned)wgs), dim3(kThreads), 0, s, p);
+    hipLaunchKernelGGL((k_crc_batch<G, true, false>), dim3((unsigned)wgs), dim3(kThreads), 0, s, p, NoLongArgs{});
   else
-    hipLaunchKernelGGL((k_crc_batch<G, false>), dim3((unsigned)wgs), dim3(kThreads), 0, s, p);
+    hipLaunchKernelGGL((k_crc_batch<G, false, false>), dim3((unsigned)wgs), dim3(kThreads), 0, s, p, NoLongArgs{});
   HIP_TRY(hipGetLastError());
   return TCRC_OK;
 }
@@ -559,6 +621,32 @@ void scratch_release(tcrc_scratch* s) {
   if (s->p) (void)hipFree(s->p);
   s->p = nullptr;
   s->bytes = 0;
+}
+
+int run_segments(tcrc_ctx* ctx, BatchParams p, const LongArgs& la, void* stream) {
+  if (!ctx) return fail(TCRC_ERR_INVALID, "null context");
+  if (p.n == 0) return TCRC_OK;
+  if (!p.base) return fail(TCRC_ERR_INVALID, "null base pointer");
+  if (la.nbuf == 0 || la.nbuf > (uint32_t)kLongLdsBuffers || (!la.bufs && la.nbuf > (uint32_t)kLongInline))
+    return fail(TCRC_ERR_INVALID, "segment launch: buffer count out of range");
+  // eight segments per wave are folded before one atomic: wider groups would queue on the accumulator
+  constexpr int G = 8;
+  const int gi = geo_index(G);
+  p.tab_main = ctx->d_tab_main[gi];
+  p.tab_aux = ctx->d_tab_aux[gi];
+  p.flags = kFlagSegments;
+  p.uniform_suffix = -1;
+  const uint64_t rounds = (p.n + (64 / G) - 1) / (64 / G);
+  const unsigned wgs = (unsigned)(rounds < (uint64_t)ctx->cus ? rounds : (uint64_t)ctx->cus);
+  ctx->st_batch_launches.fetch_add(1, std::memory_order_relaxed);
+  ctx->st_batch_buffers.fetch_add(p.n, std::memory_order_relaxed);
+  hipStream_t s = (hipStream_t)stream;
+  if (ctx->nontemporal)
+    hipLaunchKernelGGL((k_crc_batch<G, true, true>), dim3(wgs), dim3(kThreads), 0, s, p, la);
+  else
+    hipLaunchKernelGGL((k_crc_batch<G, false, true>), dim3(wgs), dim3(kThreads), 0, s, p, la);
+  HIP_TRY(hipGetLastError());
+  return TCRC_OK;
 }
 
 int run_batch(tcrc_ctx* ctx, BatchParams p, void* stream) {
@@ -638,6 +726,10 @@ int tcrc_init(int device, tcrc_ctx** out) {
       return fail(TCRC_ERR_HIP, std::string("table upload: ") + hipGetErrorString(e));
     }
   }
+  if (int rc = long_device_setup(ctx)) {
+    tcrc_shutdown(ctx);
+    return rc;
+  }
   char buf[256];
   snprintf(buf, sizeof(buf), "Supported on %s (%s, %d CUs): LDS-table batched CRC32C", prop.name, prop.gcnArchName,
            ctx->cus);
@@ -669,13 +761,13 @@ int tcrc_shutdown(tcrc_ctx* ctx) {
   for (tcrc_scratch* s : {&ctx->wal_items, &ctx->wal_item_block, &ctx->wal_misc, &ctx->wal_list_counts,
                           &ctx->wal_list_first, &ctx->wal_list_temp, &ctx->wal_frags, &ctx->host_records,
                           &ctx->host_data, &ctx->host_desc, &ctx->host_out, &ctx->host_aux, &ctx->host_blocks,
-                          &ctx->long_in, &ctx->long_desc, &ctx->long_owner, &ctx->long_after, &ctx->long_pow,
-                          &ctx->long_acc})
+                          &ctx->long_in, &ctx->long_acc})
     scratch_release(s);
   if (ctx->host_stream) (void)hipStreamDestroy(ctx->host_stream);
   for (auto& e : ctx->pin_free) (void)hipHostFree(e.first);
   if (ctx->stage_ring) (void)hipHostFree(ctx->stage_ring);
   if (ctx->zc) (void)hipHostFree(ctx->zc);
+  if (ctx->long_pin) (void)hipHostFree(ctx->long_pin);
   for (hipEvent_t ev : ctx->stage_done)
     if (ev) (void)hipEventDestroy(ev);
   delete ctx;

@@ -148,12 +148,16 @@ int upload(tcrc_ctx* ctx, tcrc_scratch* s, const void* h, size_t bytes, size_t s
 // Plain CRCs of the descriptors' spans through the long-buffer path, into h_crc.  Caller holds host_mu.
 int long_route(tcrc_ctx* ctx, const void* h_base, uint64_t base_bytes, const tcrc_desc* h_desc, uint64_t n,
                uint32_t* h_crc) {
+  // (n <= kZcMaxItems here: the results land in the zero-copy block, so the call that returns with them
+  // complete is the only synchronisation)
+  if (int rc = zc_begin(ctx)) return rc;
   if (int rc = upload(ctx, &ctx->host_data, h_base, base_bytes, 64)) return rc;
-  if (int rc = scratch_reserve(ctx, &ctx->host_out, n * 4)) return rc;
-  if (int rc = tcrc_dev_extend_long(ctx, ctx->host_data.p, h_desc, n, 0, (uint32_t*)ctx->host_out.p, ctx->host_stream))
+  if (int rc = tcrc_dev_extend_long(ctx, ctx->host_data.p, h_desc, n, 0, (uint32_t*)(ctx->zc + kZcOutOff),
+                                    ctx->host_stream)) {
+    (void)hipStreamSynchronize(ctx->host_stream);  // the upload may still be reading the caller's memory
     return rc;
-  HIP_TRY(hipMemcpyAsync(h_crc, ctx->host_out.p, n * 4, hipMemcpyDeviceToHost, ctx->host_stream));
-  HIP_TRY(hipStreamSynchronize(ctx->host_stream));
+  }
+  memcpy(h_crc, ctx->zc + kZcOutOff, n * 4);
   return TCRC_OK;
 }
 
@@ -485,12 +489,11 @@ int tcrc_extend(tcrc_ctx* ctx, uint32_t init, const void* h_data, size_t n, uint
   // Pieces of up to 256 MiB, chained through init like the callers that feed a file through
   // Extend buffer by buffer (utilities/backupable/backupable_db.cc:1434-1449).
   const size_t piece = (size_t)256 << 20;
-  if (int rc = scratch_reserve(ctx, &ctx->host_out, 64)) return rc;
+  if (int rc = zc_begin(ctx)) return rc;
   uint32_t crc = init;
   if (n <= (16u << 10)) {
     // short input: one wave walks it in a single launch, reading it from the zero-copy block (or where it
     // lies, if that is pinned memory) and leaving the result there - no copy commands at all
-    if (int rc = zc_begin(ctx)) return rc;
     const void* base = nullptr;
     if (!is_pinned(h_data, &base)) {
       memcpy(ctx->zc, h_data, n);
@@ -512,10 +515,13 @@ int tcrc_extend(tcrc_ctx* ctx, uint32_t init, const void* h_data, size_t n, uint
     d.offset = 0;
     d.len = (uint32_t)len;
     d.init = crc;
-    if (int rc = tcrc_dev_extend_long(ctx, ctx->host_data.p, &d, 1, 0, (uint32_t*)ctx->host_out.p, ctx->host_stream))
+    // the result lands in the zero-copy block: the call returns with it complete, no copy back
+    if (int rc = tcrc_dev_extend_long(ctx, ctx->host_data.p, &d, 1, 0, (uint32_t*)(ctx->zc + kZcOutOff),
+                                      ctx->host_stream)) {
+      (void)hipStreamSynchronize(ctx->host_stream);  // the upload may still be reading the caller's memory
       return rc;
-    HIP_TRY(hipMemcpyAsync(&crc, ctx->host_out.p, 4, hipMemcpyDeviceToHost, ctx->host_stream));
-    HIP_TRY(hipStreamSynchronize(ctx->host_stream));
+    }
+    memcpy(&crc, ctx->zc + kZcOutOff, 4);
     done += len;
   }
   *out = crc;

@@ -16,7 +16,7 @@ namespace tcrc_internal {
 
 // internal flag bits (above the public TCRC_F_* ones)
 constexpr uint32_t kFlagWalItems = 0x100u;  // descriptors are log records: desc.init = index inside the 32 KiB block
-constexpr uint32_t kFlagSegments = 0x200u;  // descriptors are segments of longer buffers: results are shifted and XORed
+constexpr uint32_t kFlagSegments = 0x200u;  // the items are segments of longer buffers (LongArgs): results are shifted and XORed
 constexpr uint32_t kFlagStampBefore = 0x400u;  // the result is also stored as LE32 six bytes before the buffer (log header)
 
 struct BatchParams {
@@ -38,15 +38,47 @@ struct BatchParams {
   const uint32_t* item_block;       // kFlagWalItems: 32 KiB block index of every item
   tcrc_wal_block* wal_blocks;       // kFlagWalItems: per block result (first_bad is lowered on a mismatch)
   uint64_t wal_block_base;          // kFlagWalItems: index of wal_blocks[0] in the whole image
-  const uint32_t* seg_owner;        // kFlagSegments: output slot (buffer index) of every segment
-  const uint32_t* seg_after;        // kFlagSegments: number of whole segments that follow it in its buffer
-  const uint32_t* seg_pow;          // kFlagSegments: seg_pow[q] = x^(8 * segment_len * q) mod P
   int lanes;                 // lanes per buffer to use (4, 8, 16, 64), 0 = let the engine choose
   const uint32_t* tab_main;  // 1024 dwords: Z_D set
   const uint32_t* tab_aux;   // (1+log2 G) sets of 1024 dwords: Z_4, Z_16, Z_32, ...
 };
 
 constexpr int kGeoCount = 4;
+
+// Long buffers: every buffer is cut from its END into segments of 2^seg_shift bytes (the first one may be
+// shorter); item s of the launch is segment s, and the kernel works out which buffer it belongs to and
+// where it lies from the buffer descriptors - no per-segment arrays exist anywhere.
+constexpr int kLongInline = 64;         // up to this many buffers travel in the kernel arguments
+constexpr int kLongLdsBuffers = 2048;   // buffers of one launch (their running segment counts sit in LDS)
+constexpr int kPowMinShift = 8;         // smallest segment: 256 bytes
+constexpr int kPowMaxShift = 30;        // largest: 1 GiB
+constexpr int kPowEntries = 2048;       // table T_s holds x^(8 * 2^s * i) for i < 2048
+constexpr int kPowTables = kPowMaxShift + 11 - kPowMinShift + 1;  // T_8 .. T_41: T_(s+11) is T_s's second level
+struct LongArgs {
+  uint32_t nbuf;              // buffers of this launch (<= kLongLdsBuffers)
+  uint32_t seg_shift;         // log2 of the segment length
+  uint32_t first_base;        // value of seg_first[0] (running counts may continue from an earlier launch)
+  const tcrc_desc* bufs;      // [nbuf] in device memory, or NULL: inl / inl_first below
+  const uint32_t* seg_first;  // [nbuf + 1] segments before buffer b
+  const uint32_t* pow_lo;     // T_seg_shift
+  const uint32_t* pow_hi;     // T_(seg_shift + 11)
+  uint32_t* acc;              // one 128-byte line per buffer: word 0 XOR of the shifted segment remainders,
+                              // word 1 segments arrived.  All zero before and after a launch.
+  tcrc_desc inl[kLongInline];
+  uint32_t inl_first[kLongInline];
+};
+struct NoLongArgs {};
+
+// a * b mod P (register convention bit 31 = x^0), 32 shift-and-xor steps.
+__device__ __forceinline__ uint32_t gf2_mulmod_dev(uint32_t a, uint32_t b) {
+  uint32_t prod = 0;
+#pragma unroll 8
+  for (int i = 31; i >= 0; --i) {
+    prod ^= ((a >> i) & 1u) ? b : 0u;
+    b = (b >> 1) ^ ((b & 1u) ? 0x82f63b78u : 0u);
+  }
+  return prod;
+}
 
 int fail(int code, const std::string& msg);
 
@@ -55,6 +87,10 @@ void build_tables(int G, std::vector<uint32_t>* main_tab, std::vector<uint32_t>*
 
 // Launches the batch CRC kernel for the geometry the context prefers.
 int run_batch(tcrc_ctx* ctx, BatchParams p, void* stream);
+// Launches it over the p.n segments that la describes (p.base, p.out and p.n are used).
+int run_segments(tcrc_ctx* ctx, BatchParams p, const LongArgs& la, void* stream);
+// Per-device set-up of the long-buffer path at tcrc_init (the context's GPU is current): the power tables.
+int long_device_setup(tcrc_ctx* ctx);
 
 // Makes the context's GPU the calling thread's current device for the rest of the scope and puts the
 // caller's device back afterwards (a multi-GPU host must not find its current device changed by a call).
@@ -111,9 +147,10 @@ struct tcrc_ctx {
   // long-buffer scratch (tcrc_long.hip): one call at a time per context.  Lock order: host_mu, then
   // wal_mu or long_mu.
   std::mutex long_mu;
-  tcrc_scratch long_in, long_desc, long_owner, long_after, long_pow, long_acc;
-  uint32_t long_pow_seg = 0;      // segment length the cached power table was built for
-  uint32_t long_pow_count = 0;    // entries in it
+  tcrc_scratch long_in, long_acc;
+  const uint32_t* d_pow = nullptr;  // kPowTables x kPowEntries words on this GPU (shared by its contexts, never freed)
+  uint32_t* d_static = nullptr;     // this GPU's copy of the library's static scratch (accumulator lines first)
+  char* long_pin = nullptr;         // pinned staging for the descriptors of a call with more than kLongInline buffers
   // Small host calls skip the copies: the kernel reads descriptors (and short inputs) from, and writes its
   // results to, this block of pinned host memory that the GPU addresses directly.  Guarded by host_mu.
   static constexpr size_t kZcData = (size_t)64 << 10;     // bounce area for short pageable inputs

@@ -1,18 +1,25 @@
 // Long buffers (hundreds of KiB to GiBs): the CRC of one buffer is computed by many lane
 // groups at once.  A buffer is cut, from its END, into segments of S bytes (the first one
-// may be shorter); every segment goes through the batch kernel as a buffer of its own, and
-// the segment remainders are merged with the GF(2) identity
+// may be shorter); every segment is walked by a lane group of the batch kernel as a buffer
+// of its own, and the segment remainders are merged with the GF(2) identity
 //     R(A || B) = R(A) * x^(8|B|)  xor  R(B)        (mod P)
 // i.e. a segment followed by q whole segments is multiplied by x^(8 S q) and XORed into the
 // buffer's result.  This is the role the reference's three-stream combine plays inside one
 // call of crc32c_3way (util/crc32c.cc:641-658,686-699), widened from 3 streams to thousands;
 // the caller-visible function is still crc32c::Extend (util/crc32c.cc:1226-1228), e.g. for
 // the backup engine's whole-file checksums (utilities/backupable/backupable_db.cc:1434-1449).
+//
+// One call is ONE kernel launch: the kernel derives every segment from the buffer
+// descriptors (which travel in the kernel arguments when there are at most kLongInline of
+// them), the buffers' accumulator lines clean themselves (the lane group that delivers a
+// buffer's last segment takes the value out, zeroes the line and writes the result), and
+// the powers x^(8 S q) come from tables built once per GPU.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include <string.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -23,61 +30,127 @@ using namespace tcrc_internal;
 
 namespace {
 
-struct ExpandParams {
-  const tcrc_desc* buffers;    // [nbuf]
-  const uint32_t* seg_first;   // [nbuf+1] segments before buffer b
-  uint32_t nbuf;
-  uint32_t nseg;
-  uint32_t seg_len;
-  tcrc_desc* segs;     // out [nseg]
-  uint32_t* owner;     // out [nseg]
-  uint32_t* after;     // out [nseg]
+// ---- static device memory -------------------------------------------------------------------
+// [accumulator lines of the entry point that allocates nothing | power tables T_8 .. T_41]
+// Every GPU the library runs on holds its own copy (at its own address) until the process ends.
+constexpr uint32_t kStaticAccWords = (uint32_t)kLongInline * 32u;  // one 128-byte line per buffer
+constexpr uint32_t kStaticPowWords = (uint32_t)kPowTables * (uint32_t)kPowEntries;
+constexpr uint32_t kStaticWords = kStaticAccWords + kStaticPowWords;
+static __device__ __align__(256) uint32_t scratch[kStaticWords];
+
+constexpr int kMaxDevices = 64;
+std::mutex g_static_mu;
+uint32_t* g_static_ptr[kMaxDevices] = {};  // device address of `scratch` on every GPU set up so far
+
+// T_s[i] = x^(8 * 2^s * i) mod P for s = kPowMinShift + blockIdx.x, i < kPowEntries.
+__global__ __launch_bounds__(1024) void k_pow_tables(uint32_t* tables) {
+  const uint32_t s = (uint32_t)kPowMinShift + blockIdx.x;
+  uint32_t base = 0x40000000u;  // x; squared s + 3 times: x^(2^(s+3)) = x^(8 * 2^s)
+  for (uint32_t k = 0; k < s + 3u; ++k) base = gf2_mulmod_dev(base, base);
+  for (uint32_t i = threadIdx.x; i < (uint32_t)kPowEntries; i += 1024u) {
+    uint32_t r = 0x80000000u, sq = base;
+    for (uint32_t e = i; e; e >>= 1) {
+      if (e & 1u) r = gf2_mulmod_dev(r, sq);
+      sq = gf2_mulmod_dev(sq, sq);
+    }
+    tables[(size_t)blockIdx.x * kPowEntries + i] = r;
+  }
+}
+
+// Segment length for a call: a power of two that gives every lane group of the chip (8 per wave, 16 waves
+// per CU) about one segment.  Small totals get shorter segments so that the work still spreads over the
+// CUs, but not more than about a thousand of them: every wave ends with two atomics on its buffer's
+// accumulator line, and those queue up (measured: one 4 MiB buffer takes 25 us with 2 KiB segments and 41 us
+// with 512-byte ones).
+uint32_t choose_shift(const tcrc_ctx* ctx, uint64_t total) {
+  const uint64_t groups = (uint64_t)ctx->cus * 16 * 8;
+  uint32_t shift = 9;
+  while (shift < 11 && (total >> shift) > 1024) ++shift;
+  while (shift < 16 && (total >> shift) > groups) ++shift;
+  return shift;
+}
+
+int shift_of(uint32_t segment_len, uint32_t* shift) {
+  if (segment_len < 256u || (segment_len & (segment_len - 1u)) != 0u || segment_len > (1u << kPowMaxShift))
+    return fail(TCRC_ERR_INVALID, "segment_len must be a power of two between 256 and 2^30");
+  uint32_t s = 0;
+  while ((1u << s) < segment_len) ++s;
+  *shift = s;
+  return TCRC_OK;
+}
+
+inline uint32_t segments_of(uint32_t len, uint32_t shift) {
+  return len == 0 ? 1u : (uint32_t)(((uint64_t)len + (1ull << shift) - 1) >> shift);
+}
+
+// Synchronises the stream when the scope is left on an error path: copies issued from host memory that is
+// about to be freed or reused must not stay in flight.
+struct SyncOnError {
+  hipStream_t s;
+  bool armed = false;
+  explicit SyncOnError(hipStream_t st) : s(st) {}
+  ~SyncOnError() {
+    if (armed) (void)hipStreamSynchronize(s);
+  }
 };
 
-__global__ __launch_bounds__(256) void k_expand_segments(ExpandParams p) {
-  const uint32_t s = blockIdx.x * 256u + threadIdx.x;
-  if (s >= p.nseg) return;
-  // buffer that owns segment s: last b with seg_first[b] <= s
-  uint32_t lo = 0, hi = p.nbuf;
-  while (hi - lo > 1) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if (p.seg_first[mid] <= s) lo = mid; else hi = mid;
+}  // namespace
+
+namespace tcrc_internal {
+
+int long_device_setup(tcrc_ctx* ctx) {
+  if (ctx->device < 0 || ctx->device >= kMaxDevices) return fail(TCRC_ERR_INVALID, "device index above 63");
+  std::lock_guard<std::mutex> lock(g_static_mu);
+  if (!g_static_ptr[ctx->device]) {
+    // the array's name is only a handle on the host: this GPU's copy has an address of its own
+    uint32_t* ptr = nullptr;
+    HIP_TRY(hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch)));
+    if (!ptr) return fail(TCRC_ERR_HIP, "hipGetSymbolAddress returned no address for the static scratch");
+    HIP_TRY(hipMemsetAsync(ptr, 0, (size_t)kStaticAccWords * 4, nullptr));
+    hipLaunchKernelGGL(k_pow_tables, dim3(kPowTables), dim3(1024), 0, nullptr, ptr + kStaticAccWords);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    g_static_ptr[ctx->device] = ptr;
   }
-  const uint32_t b = lo;
-  const uint32_t k = s - p.seg_first[b];
-  const uint32_t nseg = p.seg_first[b + 1] - p.seg_first[b];
-  const tcrc_desc d = p.buffers[b];
-  const uint32_t q = nseg - 1 - k;                    // whole segments after this one
-  const uint64_t end = (uint64_t)d.len - (uint64_t)q * p.seg_len;
-  const uint64_t start = end > p.seg_len ? end - p.seg_len : 0;
-  tcrc_desc o;
-  o.offset = d.offset + start;
-  o.len = (uint32_t)(end - start);
-  o.init = k == 0 ? d.init : 0xffffffffu;  // later segments start from a zero register
-  p.segs[s] = o;
-  p.owner[s] = b;
-  p.after[s] = q;
+  ctx->d_static = g_static_ptr[ctx->device];
+  ctx->d_pow = ctx->d_static + kStaticAccWords;
+  return TCRC_OK;
 }
 
-// The kernel accumulates buffer b in acc[32 b] (one accumulator per 128-byte line).
-__global__ __launch_bounds__(256) void k_long_gather(const uint32_t* acc, uint32_t* out, uint32_t n) {
-  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  if (i < n) out[i] = acc[(uint64_t)i * 32u];
+}  // namespace tcrc_internal
+
+namespace {
+
+void fill_common(const tcrc_ctx* ctx, uint32_t shift, LongArgs* la) {
+  la->seg_shift = shift;
+  la->pow_lo = ctx->d_pow + (size_t)(shift - kPowMinShift) * kPowEntries;
+  la->pow_hi = ctx->d_pow + (size_t)(shift + 11 - kPowMinShift) * kPowEntries;
 }
 
-// seg_pow[q] = x^(8 * seg_len * q), grown on demand and cached per context.
-int ensure_pow_table(tcrc_ctx* ctx, uint32_t seg_len, uint32_t count, hipStream_t s) {
-  if (ctx->long_pow_seg == seg_len && ctx->long_pow_count >= count) return TCRC_OK;
-  uint32_t want = count < 1024 ? 1024 : count + count / 2;
-  std::vector<uint32_t> t(want);
-  const uint32_t step = tcrc::gf2_xpow(8ull * seg_len);
-  t[0] = 0x80000000u;
-  for (uint32_t q = 1; q < want; ++q) t[q] = tcrc::gf2_mulmod(t[q - 1], step);
-  if (int rc = scratch_reserve(ctx, &ctx->long_pow, (size_t)want * 4)) return rc;
-  HIP_TRY(hipMemcpyAsync(ctx->long_pow.p, t.data(), (size_t)want * 4, hipMemcpyHostToDevice, s));
-  HIP_TRY(hipStreamSynchronize(s));  // t goes out of scope
-  ctx->long_pow_seg = seg_len;
-  ctx->long_pow_count = want;
+// Validates the descriptors of a call with at most kLongInline buffers and puts them into the kernel
+// arguments; returns the number of segments through *nseg.
+int plan_inline(const tcrc_ctx* ctx, const tcrc_desc* h_desc, uint32_t n, uint32_t segment_len, LongArgs* la,
+                uint64_t* nseg, uint64_t* total_bytes) {
+  uint64_t total = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    if (h_desc[i].len > (1u << 30)) return fail(TCRC_ERR_TOO_LARGE, "buffer above 1 GiB: chain calls through init");
+    total += h_desc[i].len;
+  }
+  uint32_t shift = 0;
+  if (segment_len == 0) shift = choose_shift(ctx, total);
+  else if (int rc = shift_of(segment_len, &shift)) return rc;
+  memset(la, 0, sizeof(*la));
+  fill_common(ctx, shift, la);
+  la->nbuf = n;
+  uint64_t count = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    la->inl_first[i] = (uint32_t)count;
+    la->inl[i] = h_desc[i];
+    count += segments_of(h_desc[i].len, shift);
+  }
+  if (count >= (1ull << 31)) return fail(TCRC_ERR_TOO_LARGE, "too many segments");
+  *nseg = count;
+  *total_bytes = total;
   return TCRC_OK;
 }
 
@@ -91,74 +164,89 @@ extern "C" int tcrc_dev_extend_long(tcrc_ctx* ctx, const void* d_base, const tcr
   if (n > (1u << 24)) return fail(TCRC_ERR_TOO_LARGE, "too many buffers in one long-buffer call");
   TCRC_DEVICE_SCOPE(ctx);
   hipStream_t s = (hipStream_t)stream;
-  uint64_t total = 0, longest = 0;
+  BatchParams p{};
+  p.base = (const uint8_t*)d_base;
+  p.out = d_out;
+
+  if (n <= (uint64_t)kLongInline) {
+    LongArgs la;
+    uint64_t nseg = 0, total = 0;
+    if (int rc = plan_inline(ctx, h_desc, (uint32_t)n, segment_len, &la, &nseg, &total)) return rc;
+    std::lock_guard<std::mutex> lock(ctx->long_mu);  // the accumulator lines belong to one call at a time
+    ctx->st_long_calls.fetch_add(1, std::memory_order_relaxed);
+    ctx->st_long_bytes.fetch_add(total, std::memory_order_relaxed);
+    if (ctx->long_acc.bytes < (size_t)kLongInline * 128) {
+      if (int rc = scratch_reserve(ctx, &ctx->long_acc, (size_t)kLongLdsBuffers * 128)) return rc;
+      HIP_TRY(hipMemsetAsync(ctx->long_acc.p, 0, ctx->long_acc.bytes, s));
+    }
+    la.acc = (uint32_t*)ctx->long_acc.p;
+    p.n = nseg;
+    if (int rc = run_segments(ctx, p, la, stream)) return rc;
+    HIP_TRY(hipStreamSynchronize(s));  // "returns with d_out complete"; also frees the lines for the next call
+    return TCRC_OK;
+  }
+
+  // More buffers than the kernel arguments hold: descriptors and running segment counts go to device memory,
+  // and every launch takes up to kLongLdsBuffers buffers.
+  uint64_t total = 0;
   for (uint64_t i = 0; i < n; ++i) {
     if (h_desc[i].len > (1u << 30)) return fail(TCRC_ERR_TOO_LARGE, "buffer above 1 GiB: chain calls through init");
     total += h_desc[i].len;
-    if (h_desc[i].len > longest) longest = h_desc[i].len;
   }
-  // Segment length: a power of two between 2 KiB and 64 KiB that gives every lane group of the
-  // chip (8 per wave, 16 waves per CU) about one segment.
-  uint32_t seg = segment_len;
-  if (seg == 0) {
-    const uint64_t groups = (uint64_t)ctx->cus * 16 * 8;
-    seg = 2048;
-    while (seg < 65536 && total / seg > groups) seg <<= 1;
-  }
-  if (seg < 256 || (seg & (seg - 1)) != 0) return fail(TCRC_ERR_INVALID, "segment_len must be a power of two >= 256");
-  // one staging block: the descriptors, then the running segment counts
-  std::vector<uint32_t> staging(n * 4 + n + 1);
-  memcpy(staging.data(), h_desc, n * sizeof(tcrc_desc));
-  uint32_t* first = staging.data() + n * 4;
-  uint64_t nseg = 0;
-  for (uint64_t i = 0; i < n; ++i) {
-    first[i] = (uint32_t)nseg;
-    const uint64_t k = h_desc[i].len == 0 ? 1 : (h_desc[i].len + seg - 1) / seg;
-    nseg += k;
-  }
-  first[n] = (uint32_t)nseg;
-  if (nseg >= (1ull << 31)) return fail(TCRC_ERR_TOO_LARGE, "too many segments");
+  uint32_t shift = 0;
+  if (segment_len == 0) shift = choose_shift(ctx, total);
+  else if (int rc = shift_of(segment_len, &shift)) return rc;
+  const size_t in_bytes = n * sizeof(tcrc_desc) + (n + 1) * 4;
+  constexpr size_t kPinBytes = (size_t)kLongLdsBuffers * sizeof(tcrc_desc) + ((size_t)kLongLdsBuffers + 1) * 4;
 
   std::lock_guard<std::mutex> lock(ctx->long_mu);
   ctx->st_long_calls.fetch_add(1, std::memory_order_relaxed);
   ctx->st_long_bytes.fetch_add(total, std::memory_order_relaxed);
-  if (int rc = ensure_pow_table(ctx, seg, (uint32_t)((longest + seg - 1) / seg + 1), s)) return rc;
-  const size_t in_bytes = n * sizeof(tcrc_desc) + (n + 1) * 4;
+  // staging: the context's pinned block when it is large enough, else a pageable vector (the closing
+  // synchronisation covers its copy)
+  std::vector<uint32_t> pageable;
+  uint8_t* stage;
+  if (in_bytes <= kPinBytes) {
+    if (!ctx->long_pin) HIP_TRY(hipHostMalloc((void**)&ctx->long_pin, kPinBytes, hipHostMallocDefault));
+    stage = (uint8_t*)ctx->long_pin;
+  } else {
+    pageable.resize((in_bytes + 3) / 4);
+    stage = (uint8_t*)pageable.data();
+  }
+  memcpy(stage, h_desc, n * sizeof(tcrc_desc));
+  uint32_t* first = (uint32_t*)(stage + n * sizeof(tcrc_desc));
+  uint64_t nseg = 0;
+  for (uint64_t i = 0; i < n; ++i) {
+    first[i] = (uint32_t)nseg;
+    nseg += segments_of(h_desc[i].len, shift);
+  }
+  first[n] = (uint32_t)nseg;
+  if (nseg >= (1ull << 31)) return fail(TCRC_ERR_TOO_LARGE, "too many segments");
   if (int rc = scratch_reserve(ctx, &ctx->long_in, in_bytes)) return rc;
-  if (int rc = scratch_reserve(ctx, &ctx->long_desc, nseg * sizeof(tcrc_desc))) return rc;
-  if (int rc = scratch_reserve(ctx, &ctx->long_owner, nseg * 4)) return rc;
-  if (int rc = scratch_reserve(ctx, &ctx->long_after, nseg * 4)) return rc;
-  uint8_t* in = (uint8_t*)ctx->long_in.p;
-  HIP_TRY(hipMemcpyAsync(in, staging.data(), in_bytes, hipMemcpyHostToDevice, s));
-  if (int rc = scratch_reserve(ctx, &ctx->long_acc, n * 128)) return rc;
-  HIP_TRY(hipMemsetAsync(ctx->long_acc.p, 0, n * 128, s));
-  ExpandParams e{};
-  e.buffers = (const tcrc_desc*)in;
-  e.seg_first = (const uint32_t*)(in + n * sizeof(tcrc_desc));
-  e.nbuf = (uint32_t)n;
-  e.nseg = (uint32_t)nseg;
-  e.seg_len = seg;
-  e.segs = (tcrc_desc*)ctx->long_desc.p;
-  e.owner = (uint32_t*)ctx->long_owner.p;
-  e.after = (uint32_t*)ctx->long_after.p;
-  hipLaunchKernelGGL(k_expand_segments, dim3((unsigned)((nseg + 255) / 256)), dim3(256), 0, s, e);
-  HIP_TRY(hipGetLastError());
-  BatchParams p{};
-  p.base = (const uint8_t*)d_base;
-  p.desc = e.segs;
-  p.n = nseg;
-  p.uniform_suffix = -1;
-  p.flags = kFlagSegments;
-  p.lanes = 8;  // eight segments per wave are folded before one atomic: wider groups would queue on the accumulator
-  p.out = (uint32_t*)ctx->long_acc.p;
-  p.seg_owner = e.owner;
-  p.seg_after = e.after;
-  p.seg_pow = (const uint32_t*)ctx->long_pow.p;
-  if (int rc = run_batch(ctx, p, stream)) return rc;
-  hipLaunchKernelGGL(k_long_gather, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
-                     (const uint32_t*)ctx->long_acc.p, d_out, (uint32_t)n);
-  HIP_TRY(hipGetLastError());
-  // the staging block was copied with pageable-memory semantics; make sure it is consumed
+  if (ctx->long_acc.bytes < (size_t)kLongLdsBuffers * 128) {
+    if (int rc = scratch_reserve(ctx, &ctx->long_acc, (size_t)kLongLdsBuffers * 128)) return rc;
+    HIP_TRY(hipMemsetAsync(ctx->long_acc.p, 0, ctx->long_acc.bytes, s));
+  }
+  SyncOnError guard(s);
+  HIP_TRY(hipMemcpyAsync(ctx->long_in.p, stage, in_bytes, hipMemcpyHostToDevice, s));
+  guard.armed = true;
+  const tcrc_desc* d_bufs = (const tcrc_desc*)ctx->long_in.p;
+  const uint32_t* d_first = (const uint32_t*)((const uint8_t*)ctx->long_in.p + n * sizeof(tcrc_desc));
+  for (uint64_t b0 = 0; b0 < n; b0 += kLongLdsBuffers) {
+    const uint32_t nb = (uint32_t)(n - b0 < (uint64_t)kLongLdsBuffers ? n - b0 : (uint64_t)kLongLdsBuffers);
+    LongArgs la;
+    memset(&la, 0, sizeof(la));
+    fill_common(ctx, shift, &la);
+    la.nbuf = nb;
+    la.first_base = first[b0];
+    la.bufs = d_bufs + b0;
+    la.seg_first = d_first + b0;
+    la.acc = (uint32_t*)ctx->long_acc.p;  // launches of one stream run one after the other: the lines are free again
+    p.n = first[b0 + nb] - first[b0];
+    p.out = d_out + b0;
+    if (int rc = run_segments(ctx, p, la, stream)) return rc;
+  }
+  guard.armed = false;
   HIP_TRY(hipStreamSynchronize(s));
   return TCRC_OK;
 }
