@@ -134,6 +134,18 @@ int tcrc_dev_batch_verify(tcrc_ctx* ctx, const void* d_base, const tcrc_desc* d_
 int tcrc_dev_extend_long(tcrc_ctx* ctx, const void* d_base, const tcrc_desc* h_desc, uint64_t n, uint32_t segment_len,
                          uint32_t* d_out, void* stream);
 
+/* tcrc_dev_extend_long for callers that cannot allocate (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments and results,
+ * with these limits: at most 64 buffers per call (TCRC_ERR_TOO_LARGE beyond), each up to 1 GiB.  The
+ * call only enqueues one memset and one kernel on `stream`: it allocates nothing, issues no copy command
+ * and does not synchronise, so d_out is complete once the stream has run (the caller synchronises).
+ * The partial results live in 8 KiB of the library's static device memory (each GPU holds its own copy
+ * for the life of the process; the same array holds the 272 KiB of power tables built at tcrc_init).
+ * Every call on a GPU shares those 8 KiB: calls that overlap on one GPU - different streams without an
+ * event between them, different contexts, different threads - race and give wrong values. */
+int tcrc_dev_extend_long_noalloc(tcrc_ctx* ctx, const void* d_base, const tcrc_desc* h_desc, uint64_t n,
+                                 uint32_t segment_len, uint32_t* d_out, void* stream);
+
 /* ---- write-ahead-log images ------------------------------------------------------ */
 /* How the structural walk of one 32 KiB log block ended (db/log_reader.cc:314-384). */
 #define TCRC_WAL_END_CLEAN 0          /* records fill the block exactly */

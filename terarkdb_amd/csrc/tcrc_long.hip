@@ -250,3 +250,33 @@ extern "C" int tcrc_dev_extend_long(tcrc_ctx* ctx, const void* d_base, const tcr
   HIP_TRY(hipStreamSynchronize(s));
   return TCRC_OK;
 }
+
+// The same for callers that must not allocate (a HIP graph being captured, a serving loop, a harness that
+// forbids it): at most kLongInline buffers, accumulator lines in the library's static device memory, one
+// memset and one kernel enqueued on `stream`, nothing else - no allocation, no copy command, no
+// synchronisation.  Results are in d_out once the stream has run.  Calls that overlap on one GPU share the
+// static lines and race: keep them on one stream, or order them with events.
+extern "C" int tcrc_dev_extend_long_noalloc(tcrc_ctx* ctx, const void* d_base, const tcrc_desc* h_desc, uint64_t n,
+                                            uint32_t segment_len, uint32_t* d_out, void* stream) {
+  if (!ctx) return fail(TCRC_ERR_INVALID, "null context");
+  if (n == 0) return TCRC_OK;
+  if (!d_base || !h_desc || !d_out) return fail(TCRC_ERR_INVALID, "null argument");
+  if (n > (uint64_t)kLongInline)
+    return fail(TCRC_ERR_TOO_LARGE, "tcrc_dev_extend_long_noalloc takes at most 64 buffers per call");
+  if (!ctx->d_static) return fail(TCRC_ERR_INVALID, "context without static device memory");
+  TCRC_DEVICE_SCOPE(ctx);
+  LongArgs la;
+  uint64_t nseg = 0, total = 0;
+  if (int rc = plan_inline(ctx, h_desc, (uint32_t)n, segment_len, &la, &nseg, &total)) return rc;
+  ctx->st_long_calls.fetch_add(1, std::memory_order_relaxed);
+  ctx->st_long_bytes.fetch_add(total, std::memory_order_relaxed);
+  hipStream_t s = (hipStream_t)stream;
+  // the lines keep whatever an earlier call (or one that was cut short) left in them
+  HIP_TRY(hipMemsetAsync(ctx->d_static, 0, (size_t)kStaticAccWords * 4, s));
+  la.acc = ctx->d_static;
+  BatchParams p{};
+  p.base = (const uint8_t*)d_base;
+  p.out = d_out;
+  p.n = nseg;
+  return run_segments(ctx, p, la, stream);
+}

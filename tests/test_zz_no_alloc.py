@@ -1,0 +1,71 @@
+"""The long-buffer entry point that allocates nothing (tcrc_dev_extend_long_noalloc) against the entry point
+it is a variant of (tcrc_dev_extend_long) and against the CPU oracle: two calls in a row, the second smaller,
+so that whatever the first left in the shared static lines would show."""
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import gpu_util as G
+    e = G.engine()
+    yield e
+    e.close()
+
+
+def both(eng, dev, offs, lens, inits, seg=0):
+    n = len(offs)
+    a = torch.full((n,), 0x5a5a5a5a, dtype=torch.int32, device="cuda")
+    b = torch.full((n,), 0x3c3c3c3c, dtype=torch.int32, device="cuda")
+    eng.extend_long(dev, offs, lens, inits, a, segment_len=seg, noalloc=True)  # only enqueues
+    torch.cuda.synchronize()
+    eng.extend_long(dev, offs, lens, inits, b, segment_len=seg)
+    torch.cuda.synchronize()
+    return a.cpu().numpy().view(np.uint32), b.cpu().numpy().view(np.uint32)
+
+
+def test_two_calls_in_a_row_second_smaller(eng):
+    import gpu_util as G
+    host = O.splitmix(16 * (1 << 20) + 64, 909)
+    dev = G.to_dev(host)
+    rng = np.random.default_rng(5)
+    # first call: 64 buffers (the maximum) of 256 KiB +- a few bytes at odd offsets, random inits
+    offs = [i * (1 << 18) + int(rng.integers(0, 16)) for i in range(64)]
+    lens = [(1 << 18) - 40 + int(rng.integers(0, 24)) for _ in range(64)]
+    inits = [int(rng.integers(0, 2**32)) for _ in range(64)]
+    for seg in (0, 256, 65536):
+        got, ref = both(eng, dev, offs, lens, inits, seg)
+        want = O.batch_extend(host, np.array(offs, np.uint64), np.array(lens, np.uint32), np.array(inits, np.uint32))
+        assert (got == want).all() and (ref == want).all(), seg
+        # second call, smaller: three short buffers, one of them empty
+        offs2, lens2, inits2 = [7, 300001, 5], [70001, 4097, 0], [0, 0xdeadbeef, 0x1234]
+        got2, ref2 = both(eng, dev, offs2, lens2, inits2, seg)
+        want2 = O.batch_extend(host, np.array(offs2, np.uint64), np.array(lens2, np.uint32), np.array(inits2, np.uint32))
+        assert (got2 == want2).all() and (ref2 == want2).all(), seg
+
+
+def test_limits_and_no_allocation_side_effects(eng):
+    import terarkdb_amd.capi as capi
+    import gpu_util as G
+    host = O.splitmix(1 << 20, 3)
+    dev = G.to_dev(host)
+    out = torch.zeros(65, dtype=torch.int32, device="cuda")
+    with pytest.raises(capi.TcrcError, match="at most 64 buffers"):
+        eng.extend_long(dev, [0] * 65, [1024] * 65, [0] * 65, out, noalloc=True)
+    with pytest.raises(capi.TcrcError, match="segment_len"):
+        eng.extend_long(dev, [0], [1024], [0], out, segment_len=384, noalloc=True)
+    # device memory in use does not change over a burst of calls (nothing is allocated or freed)
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(50):
+        eng.extend_long(dev, [3, 9], [1 << 19, 77777], [0, 1], out, noalloc=True)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 == free1
+    want = O.batch_extend(host, np.array([3, 9], np.uint64), np.array([1 << 19, 77777], np.uint32), np.array([0, 1], np.uint32))
+    assert (out[:2].cpu().numpy().view(np.uint32) == want).all()
