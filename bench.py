@@ -9,9 +9,13 @@ the stored trailer value.  Inputs are resident in HBM before the timed region.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-With N > 1 every rank owns one GPU and one 1 GiB shard of the corpus (block-range sharding,
-weak scaling); no data moves between GPUs, and the only collective is one 24-byte all-gather (RCCL)
-of {mismatches, blocks checked, first bad block} inside the timed region.
+With N = 1 the corpus is the 1 GiB batch (131 072 blocks).  With N > 1 it is ONE 64 GiB corpus of the
+same stream (8 388 608 blocks), sharded by contiguous block range: rank r owns one GPU and the blocks
+shard_range(8 388 608, r, N), i.e. 32 / 16 / 8 GiB per GPU at N = 2 / 4 / 8 (strong scaling).  No data moves
+between GPUs, and the only collective is one 24-byte all-gather (RCCL) of {mismatches, blocks checked,
+first bad block} inside the timed region.  Before the timed region every rank compares the XOR of the
+trailers of every GiB it owns with tests/golden/corpus64_folds.json (GiB 0: the value captured from a build
+of the reference; the others: made by the CPU checker with tools/make_corpus_folds.py).
 
 Rank 0 prints ONE JSON line.
 """
@@ -30,11 +34,11 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 BLOCK_LEN = 8192
-N_BLOCKS = 131072            # 1 GiB
+PER_GIB = 131072             # blocks per GiB
 TYPE_BYTE = 0                # kNoCompression
 SPLITMIX_STATE = 301
-XOR_OF_MASKED = 0x0744A84E   # fold of all trailers of this corpus, captured from a build of the reference
-N_CORRUPT = 5                # seeded single-bit corruptions per shard (verification must find exactly these)
+XOR_OF_MASKED = 0x0744A84E   # fold of all trailers of the first GiB, captured from a build of the reference
+CORRUPT_PER_GIB = 5          # seeded single-bit corruptions per GiB of corpus (verification must find exactly these)
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E peak
 
 
@@ -88,16 +92,12 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--shard-gib", type=int, default=1,
-                    help="GiB of 8 KiB blocks per GPU (1 = the headline batch; 8 = the 64 GiB-over-8-GPUs shard)")
+    ap.add_argument("--corpus-gib", type=int, default=0,
+                    help="GiB of 8 KiB blocks in the whole corpus, split over the ranks by block range "
+                         "(default: 1 with one GPU = the headline batch, 64 with several)")
     ap.add_argument("--settle-seconds", type=float, default=2.5,
                     help="untimed run of the same launches before the warm-up steps (clock ramp)")
     args = ap.parse_args()
-    if not 1 <= args.shard_gib <= 16:
-        raise SystemExit("--shard-gib must be between 1 and 16")
-    global N_BLOCKS
-    PREFIX_BLOCKS = N_BLOCKS  # the captured fold covers the first GiB of the stream
-    N_BLOCKS = N_BLOCKS * args.shard_gib
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -113,37 +113,61 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
 
-    from terarkdb_amd.synth import splitmix_dev
+    from terarkdb_amd.synth import splitmix_fill
+    from terarkdb_amd.sharding import gather_verify_counts, shard_range
     import terarkdb_amd.capi as capi
 
+    corpus_gib = args.corpus_gib or (1 if world == 1 else 64)
+    if not 1 <= corpus_gib <= 64 * max(1, world):
+        raise SystemExit("--corpus-gib out of range")
+    TOTAL_BLOCKS = corpus_gib * PER_GIB
+    lo, hi = shard_range(TOTAL_BLOCKS, rank, world)
+    N_BLOCKS = hi - lo
+    if N_BLOCKS * BLOCK_LEN > 200 << 30:
+        raise SystemExit("shard does not fit one GPU")
+
     eng = capi.Engine(local_rank)
-    # every rank checks its own shard of the corpus: shard r is the stream with state 301 + r
-    state = SPLITMIX_STATE + rank
-    data = splitmix_dev(N_BLOCKS * BLOCK_LEN, state)
+    # this rank's block range of the one corpus: the splitmix stream with state 301 from word lo * 1024 on
+    data = torch.empty(N_BLOCKS * BLOCK_LEN, dtype=torch.uint8, device="cuda")
+    splitmix_fill(data, SPLITMIX_STATE, first_word=lo * (BLOCK_LEN // 8))
     stored = torch.zeros(N_BLOCKS, dtype=torch.int32, device="cuda")
     out = torch.zeros(N_BLOCKS, dtype=torch.int32, device="cuda")
     counts = torch.zeros(capi.CNT_WORDS, dtype=torch.int64, device="cuda")
 
-    # -- parity gate (untimed): stamp, compare the fold of all trailers of shard 0 with the value captured from a
-    #    build of the reference, then seed corruptions -------------------------------------------------------
+    # -- parity gate (untimed): stamp; the fold of the trailers of every GiB this rank owns whole, and the
+    #    sampled trailers in its range, must equal the fixture; fresh stamps must verify clean ----------------
     eng.blocks_stamp(data, N_BLOCKS, BLOCK_LEN, BLOCK_LEN, stored, suffix_byte=TYPE_BYTE, flags=capi.F_MASK)
     torch.cuda.synchronize()
     host_tr = stored.cpu().numpy().view(np.uint32)
-    if rank == 0:
-        fold = int(np.bitwise_xor.reduce(host_tr[:PREFIX_BLOCKS]))
-        if fold != XOR_OF_MASKED:
-            raise SystemExit(f"parity gate failed: xor of trailers {fold:08x} != {XOR_OF_MASKED:08x}")
-    # the other shards (their own streams) have no captured fold: their stamps must at least verify clean
+    fixture = json.load(open(os.path.join(ROOT, "tests", "golden", "corpus64_folds.json")))
+    assert int(fixture["xor_of_masked_per_gib"][0], 16) == XOR_OF_MASKED
+    gibs_checked = 0
+    for g in range((lo + PER_GIB - 1) // PER_GIB, hi // PER_GIB):
+        if g >= len(fixture["xor_of_masked_per_gib"]):
+            break
+        fold = int(np.bitwise_xor.reduce(host_tr[g * PER_GIB - lo:(g + 1) * PER_GIB - lo]))
+        if fold != int(fixture["xor_of_masked_per_gib"][g], 16):
+            raise SystemExit(f"parity gate failed on rank {rank}: xor of the trailers of GiB {g} is {fold:08x}, "
+                             f"fixture says {fixture['xor_of_masked_per_gib'][g]}")
+        gibs_checked += 1
+    for b, want in fixture["trailer_of_block"].items():
+        if lo <= int(b) < hi and int(host_tr[int(b) - lo]) != int(want, 16):
+            raise SystemExit(f"parity gate failed on rank {rank}: trailer of block {b}")
+    if gibs_checked == 0:
+        raise SystemExit(f"rank {rank} owns no whole GiB of the corpus: nothing to check its trailers against")
     eng.counts_reset(counts)
     eng.blocks_verify(data, N_BLOCKS, BLOCK_LEN, BLOCK_LEN, counts, expected=stored, out=out, suffix_byte=TYPE_BYTE)
     torch.cuda.synchronize()
     c0 = counts.cpu().tolist()
     if c0[0] != 0 or c0[2] != N_BLOCKS or not torch.equal(out, stored):
         raise SystemExit(f"parity gate failed: fresh stamps do not verify ({c0})")
-    bad_blocks = np.sort(np.random.default_rng(1000 + rank).choice(N_BLOCKS, N_CORRUPT, replace=False))
+    # seeded corruptions over the WHOLE corpus; every rank flips the ones that fall into its range
+    n_corrupt = CORRUPT_PER_GIB * corpus_gib
+    bad_blocks = np.sort(np.random.default_rng(1000).choice(TOTAL_BLOCKS, n_corrupt, replace=False))
     flat = data.view(-1)
     for b in bad_blocks:
-        flat[int(b) * BLOCK_LEN + 100] ^= 0x80
+        if lo <= int(b) < hi:
+            flat[(int(b) - lo) * BLOCK_LEN + 100] ^= 0x80
     torch.cuda.synchronize()
 
     stream = torch.cuda.current_stream().cuda_stream
@@ -155,9 +179,9 @@ def main():
     # Touch every other op of the timed region once first, so that no first-use set-up cost lands inside
     # it - or between the warm-up and it: a few milliseconds of idle GPU are enough for the clocks to drop,
     # and the launches after that run up to 10 % slower for the next hundred launches.
-    from terarkdb_amd.sharding import gather_verify_counts
+    shard_lo = lambda r: shard_range(TOTAL_BLOCKS, r, world)[0]  # noqa: E731
     step()
-    gather_verify_counts(counts, lambda r: r * N_BLOCKS)
+    gather_verify_counts(counts, shard_lo)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     e1.record()
@@ -169,10 +193,11 @@ def main():
     # same launches first lets the timed steps see the steady state a long verification scan runs in.
     t_settle = time.perf_counter()
     chunk_ms = []
+    per_chunk = max(4, 100 * PER_GIB // N_BLOCKS)  # about 17 ms of launches per chunk
     while True:
         c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         c0.record()
-        for _ in range(100):
+        for _ in range(per_chunk):
             step()
         c1.record()
         torch.cuda.synchronize()
@@ -200,7 +225,7 @@ def main():
     t_enq = time.perf_counter()
     # the path's only exchange: every rank's {mismatches, first bad block, checked}, one all-gather (RCCL)
     # of the engine's device counter block; the copy to the host waits for the K launches
-    totals = gather_verify_counts(counts, lambda r: r * N_BLOCKS)
+    totals = gather_verify_counts(counts, shard_lo)
     t_cnt = time.perf_counter()
     # That all-gather is the closing barrier: no rank gets its result before every rank has contributed its
     # counters, which a rank's stream produces only after its K launches.  A second collective would only add
@@ -216,21 +241,21 @@ def main():
         elapsed = float(tmax.item())
 
     mism, checked = totals.mismatches, totals.checked
-    if mism != N_CORRUPT * args.steps * world or checked != N_BLOCKS * args.steps * world:
+    if mism != n_corrupt * args.steps or checked != TOTAL_BLOCKS * args.steps:
         raise SystemExit(f"verification miscounted: {mism} mismatches / {checked} checked")
-    want_first = int(np.sort(np.random.default_rng(1000).choice(N_BLOCKS, N_CORRUPT, replace=False))[0])
+    want_first = int(bad_blocks[0])
     if totals.first_bad != want_first:
         raise SystemExit(f"first bad block {totals.first_bad} != {want_first}")
 
     avg_ms = ev_start.elapsed_time(ev_end) / args.steps  # average launch duration over the timed region
-    alg_bytes = N_BLOCKS * (BLOCK_LEN + 1)  # bytes covered by the CRC: block + type byte
+    alg_bytes = N_BLOCKS * (BLOCK_LEN + 1)  # bytes covered by the CRC in this rank's launch: block + type byte
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-    value = world * args.steps * alg_bytes / elapsed / 1e9
+    value = args.steps * TOTAL_BLOCKS * (BLOCK_LEN + 1) / elapsed / 1e9  # all ranks' units / slowest rank's time
 
     if rank == 0:
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath) and args.shard_gib == 1:  # the counters were collected on the 1 GiB launch
+        if os.path.exists(tpath) and N_BLOCKS == PER_GIB:  # the counters were collected on the 1 GiB launch
             try:
                 traffic = json.load(open(tpath)).get("bytes_per_launch")
             except Exception:
@@ -238,11 +263,16 @@ def main():
         line = {
             "metric": "device-resident masked-CRC32C GB/s, 8 KiB blocks",
             "value": round(value, 1), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "strong" if world > 1 else "weak",
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": f"{args.shard_gib} GiB batch of 8 KiB SST data blocks per GPU ({N_BLOCKS} blocks, type byte 0): "
-                                   "masked CRC32C stamped and verified against stored trailers",
-                       "settle_seconds_untimed": args.settle_seconds, "block_len": BLOCK_LEN, "blocks_per_gpu": N_BLOCKS, "sharding": "block range per GPU",
+            "config": {"workload": (f"{corpus_gib} GiB corpus of 8 KiB SST data blocks ({TOTAL_BLOCKS} blocks, type byte 0)"
+                                    + (f" sharded by block range over {world} GPUs" if world > 1 else " on one GPU")
+                                    + ": masked CRC32C stamped and verified against stored trailers"),
+                       "settle_seconds_untimed": args.settle_seconds, "block_len": BLOCK_LEN,
+                       "corpus_blocks": TOTAL_BLOCKS, "blocks_on_rank0": N_BLOCKS,
+                       "sharding": "contiguous block range per GPU", "gib_folds_checked_on_rank0": gibs_checked,
+                       "seeded_corruptions": n_corrupt,
                        "collective": "one all-gather of {mismatches, checked, first_bad} (24 B per rank)" if dist else "none"},
             "pct_hbm_peak": round(100.0 * value / (HBM_PEAK_GBS * world), 2),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -75,3 +75,19 @@ def test_two_ranks_gloo_allreduce_of_verify_counters():
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
         assert "ok" in o
+
+
+def test_sixty_four_gib_corpus_shards_own_whole_gibs():
+    """bench.py --gpus N: one 64 GiB corpus, rank r owns shard_range(8 388 608, r, N); at N = 2, 4, 8 every GiB
+    (the unit the trailer folds of tests/golden/corpus64_folds.json are kept in) belongs whole to one rank, and
+    the seeded corruptions are counted exactly once."""
+    total, per_gib = 64 * 131072, 131072
+    bad = np.sort(np.random.default_rng(1000).choice(total, 5 * 64, replace=False))
+    for world in (2, 4, 8):
+        owned, found = [], 0
+        for r in range(world):
+            lo, hi = shard_range(total, r, world)
+            assert lo % per_gib == 0 and hi % per_gib == 0 and (hi - lo) * 8192 == (64 // world) << 30
+            owned += list(range(lo // per_gib, hi // per_gib))
+            found += int(((bad >= lo) & (bad < hi)).sum())
+        assert owned == list(range(64)) and found == len(bad)
