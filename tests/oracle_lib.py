@@ -287,26 +287,32 @@ def wal_scan_blocks(img, log_number):
     return out
 
 
+def write_edge_records(t, recycle):
+    """Appends to the OracleLog t records placed to produce every trailer length 0..10 and the fragment edge
+    sizes (db/log_test.cc:293-351)."""
+    hs = 11 if recycle else 7
+    for sz in (0, 1, 32768 - hs, 32768 - hs + 1, 65536, 100000, 32761, 32762):
+        t.write(big_string(b"e%d." % sz, sz))
+    for trailer in range(0, 11):
+        # pad the current block so that exactly `trailer` bytes stay free after a record
+        used = t.written_bytes() % 32768
+        room = 32768 - used
+        body = room - hs - trailer
+        if body < 0:
+            t.write(big_string(b"p", room + 100))
+            used = t.written_bytes() % 32768
+            body = 32768 - used - hs - trailer
+        t.write(big_string(b"t%d." % trailer, body))
+        t.write(b"after-trailer")
+
+
 def build_wal_image(recycle, log_number=123, n_random=500, seed=301, edge=True):
     """A log image like db/log_test.cc's RandomRead (Random(seed).Skewed(17) sizes) plus
     records placed to produce every trailer length 0..10 and the fragment edge sizes."""
     t = OracleLog(recycle=recycle, log_number=log_number)
     rnd = Random(seed)
-    hs = 11 if recycle else 7
     if edge:
-        for sz in (0, 1, 32768 - hs, 32768 - hs + 1, 65536, 100000, 32761, 32762):
-            t.write(big_string(b"e%d." % sz, sz))
-        for trailer in range(0, 11):
-            # pad the current block so that exactly `trailer` bytes stay free after a record
-            used = t.written_bytes() % 32768
-            room = 32768 - used
-            body = room - hs - trailer
-            if body < 0:
-                t.write(big_string(b"p", room + 100))
-                used = t.written_bytes() % 32768
-                body = 32768 - used - hs - trailer
-            t.write(big_string(b"t%d." % trailer, body))
-            t.write(b"after-trailer")
+        write_edge_records(t, recycle)
     for i in range(n_random):
         t.write(big_string(number_string(i), rnd.skewed(17)))
     img = t.contents()
