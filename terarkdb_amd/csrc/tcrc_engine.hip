@@ -56,26 +56,274 @@ typedef v4u v4u_any __attribute__((aligned(1)));
 
 // 16 bytes from any address: one global_load_dwordx4 (gfx950 handles unaligned vector loads).
 // NT marks the line as streamed-once.
+// The pointer is cast to the global address space: a generic pointer makes the compiler emit flat loads, which
+// also occupy the LDS queue and force every wait to be a full one.
+typedef const v4u_any __attribute__((address_space(1)))* gptr16;
 template <bool NT>
 __device__ __forceinline__ uint4 load16(const uint8_t* p) {
   v4u v;
   if (NT) {
-    v = __builtin_nontemporal_load((const v4u_any*)p);
+    v = __builtin_nontemporal_load((gptr16)p);
   } else {
-    v = *(const v4u_any*)p;
+    v = *(gptr16)p;
   }
   return make_uint4(v.x, v.y, v.z, v.w);
 }
 
-// Z_D via the replicated tables; A = lds + (lane & 31).
-__device__ __forceinline__ uint32_t fold_main(const uint32_t* A, uint32_t c) {
-  return A[(c & 0xffu) * 32u] ^ A[8192u + ((c >> 8) & 0xffu) * 32u] ^ A[16384u + ((c >> 16) & 0xffu) * 32u] ^
-         A[24576u + (c >> 24) * 32u];
+// Z_D via the replicated tables.  LDS layout of the main set (128 KiB): entry b of the pair (T0, T1) is the 256
+// bytes at b * 256 - 32 replicas of T0[b], then 32 replicas of T1[b] - and the pair (T2, T3) follows at 64 KiB
+// in the same form.  The byte address of a lookup is then (state byte << 8) | (lane mod 32) * 4 | region bit 16,
+// which ONE byte-permute instruction forms from the state and a per-lane constant (the odd table of a pair is
+// the instruction's immediate offset 128); lane l still only touches bank l mod 32.
+// LB = (lane mod 32) * 4 | 0x10000.  v_perm_b32: result byte i = selector byte i picks 0-3 from LB, 4-7 from
+// c, 0x0c = zero.
+__device__ __forceinline__ uint32_t fold_main(const uint32_t* lds, uint32_t LB, uint32_t c) {
+  const char* base = (const char*)lds;
+  const uint32_t a0 = __builtin_amdgcn_perm(c, LB, 0x0c0c0400u);
+  const uint32_t a1 = __builtin_amdgcn_perm(c, LB, 0x0c0c0500u);
+  const uint32_t a2 = __builtin_amdgcn_perm(c, LB, 0x0c020600u);
+  const uint32_t a3 = __builtin_amdgcn_perm(c, LB, 0x0c020700u);
+  return *(const uint32_t*)(base + a0) ^ *(const uint32_t*)(base + a1 + 128) ^ *(const uint32_t*)(base + a2) ^
+         *(const uint32_t*)(base + a3 + 128);
 }
 
 // Z_n via one unreplicated 4 KiB set.
 __device__ __forceinline__ uint32_t fold_aux(const uint32_t* t, uint32_t c) {
   return t[c & 0xffu] ^ t[256u + ((c >> 8) & 0xffu)] ^ t[512u + ((c >> 16) & 0xffu)] ^ t[768u + (c >> 24)];
+}
+
+// The remainder of one span per lane group: bytes [ptr, ptr + len) fed to the register ~init.  Returns the
+// register BEFORE the final inversion (and before any suffix byte), meaningful on the last lane of every
+// group whose `valid` is set; groups that are not valid walk nothing.  All 64 lanes of the wave must call it
+// together (the row count is agreed on with shuffles).  keep_tail: load the burst that holds the last row
+// with the default cache policy (something is about to be stored right behind the span).
+// reduction sets, then x^(-8t) * x^(32 l / UL) for t < D, l < UL
+template <int G> struct AuxDwords {
+  static constexpr int value = (1 + Geo<G>::kLog2) * 1024 + 16 * G * (G <= 16 ? 4 : 1);
+};
+
+template <int G, bool NT>
+__device__ __forceinline__ uint32_t span_remainder(const uint32_t* lds, uint32_t LB, int lane, const uint8_t* ptr,
+                                                   uint32_t len, uint32_t init, bool valid, bool keep_tail) {
+  constexpr int D = 16 * G;
+  constexpr int LOG2G = Geo<G>::kLog2;
+  // lanes of a group that share the un-shift multiplication (a whole wave per buffer keeps it on one lane:
+  // its table would not fit next to the others, and its buffers are long enough not to care)
+  constexpr int UL = G <= 16 ? 4 : 1;
+  const int j = lane & (G - 1);
+  const uint32_t* aux = lds + kMainDwords;
+  const uint32_t r0 = ~init;
+  const bool live = valid && len >= 16;  // shorter messages take the byte path at the end
+  const uint32_t elen = live ? len : 0u;
+    // Rows are aligned to D-byte ADDRESS boundaries, so every 16-byte load is aligned and every
+  // row of a buffer is whole cache lines.  The bytes of the first row before the message and of
+  // the last row after it are read (same lines as message bytes) and masked to zero: leading
+  // zeros leave a CRC remainder unchanged, the `tpad` trailing ones are undone after the
+  // reduction by one multiplication with x^(-8 tpad).
+  const uint32_t a0 = live ? (uint32_t)((uintptr_t)ptr & (uintptr_t)(D - 1)) : 0u;
+  const uint32_t span = a0 + elen;
+  const uint32_t R = (span + D - 1) / D;
+  const uint32_t tpad = R * D - span;
+  uint32_t Rmax = R;
+#pragma unroll
+  for (int o = 32; o >= G; o >>= 1) {
+    const uint32_t other = __shfl_xor(Rmax, o);
+    Rmax = other > Rmax ? other : Rmax;
+  }
+  // the same in every lane now: kept in a scalar register, so that the row loops and the row classes
+  // below cost scalar instructions
+  Rmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)Rmax);
+  // A buffer with fewer rows than the longest of its wave starts later, so that all end together.
+  // message offset of this lane's column in row r is m0 + r*D
+  const int m0 = 16 * j - (int)a0 - (int)((Rmax - R) * D);
+  uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+
+  auto fold_plain = [&](const uint4& v) {
+    s0 = fold_main(lds, LB, s0) ^ v.x;
+    s1 = fold_main(lds, LB, s1) ^ v.y;
+    s2 = fold_main(lds, LB, s2) ^ v.z;
+    s3 = fold_main(lds, LB, s3) ^ v.w;
+  };
+  // A column that may stick out of the message at either end or hold some of its first four
+  // bytes (which carry the initial register): loaded only if it overlaps the message ...
+  auto load_checked = [&](uint32_t r, bool keep) -> uint4 {
+    const int m = m0 + (int)(r * D);
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (live && m > -16 && m < (int)elen) v = (NT && !keep) ? load16<true>(ptr + m) : load16<false>(ptr + m);
+    return v;
+  };
+  // ... and trimmed to the message, with the initial register folded into message bytes 0..3.
+  auto fold_checked = [&](uint4 v, uint32_t r) {
+    const int m = m0 + (int)(r * D);
+    if (live && m > -16 && m < (int)elen && (m < 4 || m + 16 > (int)elen)) {
+      unsigned long long lo = ((unsigned long long)v.y << 32) | v.x;
+      unsigned long long hi = ((unsigned long long)v.w << 32) | v.z;
+      if (m < 0) {  // bytes [0, -m) precede the message
+        const uint32_t k = (uint32_t)(-m);
+        if (k >= 8u) {
+          lo = 0;
+          hi &= ~0ull << (8u * (k - 8u));
+        } else {
+          lo &= ~0ull << (8u * k);
+        }
+      }
+      if (m + 16 > (int)elen) {  // only the first `keep` bytes belong to the message
+        const uint32_t keep = elen - (uint32_t)m;
+        if (keep <= 8u) {
+          hi = 0;
+          if (keep < 8u) lo &= (1ull << (8u * keep)) - 1ull;
+        } else {
+          hi &= (1ull << (8u * (keep - 8u))) - 1ull;
+        }
+      }
+      if (m < 4) {  // message bytes 0..3 sit at column bytes -m .. -m+3
+        if (m >= 0) {
+          lo ^= (unsigned long long)(r0 >> (8 * m));
+        } else {
+          const uint32_t k = (uint32_t)(-m);
+          if (k < 8u) {
+            lo ^= (unsigned long long)r0 << (8u * k);
+            if (k > 4u) hi ^= (unsigned long long)(r0 >> (64u - 8u * k));
+          } else {
+            hi ^= (unsigned long long)r0 << (8u * (k - 8u));
+          }
+        }
+      }
+      v = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+    }
+    fold_plain(v);
+  };
+  // Rows go in bursts of four: four 16-byte loads per lane are issued back to back (512
+  // contiguous bytes per buffer), then folded in order as they arrive.  Bursts without overlap
+  // inside a wave measured faster than keeping loads in flight across the folds; the other
+  // waves of the CU cover the latency.  The Rmax mod 4 odd rows come first, one burst.
+  uint32_t r = 0;
+  // The common shape - every buffer of the wave starts and ends on a row boundary and has the
+  // same number of rows, a multiple of four - needs no per-group checks at all: only lane 0 of
+  // each group folds the initial register into its first dword.
+  if ((Rmax & 3u) == 0u && __all(live && a0 == 0u && tpad == 0u && R == Rmax)) {
+    const uint8_t* q = ptr + 16 * j;
+    {
+      uint4 a = load16<NT>(q);
+      const uint4 b = load16<NT>(q + D);
+      const uint4 c = load16<NT>(q + 2 * D);
+      const uint4 d = load16<NT>(q + 3 * D);
+      if (j == 0) a.x ^= r0;
+      fold_plain(a);
+      fold_plain(b);
+      fold_plain(c);
+      fold_plain(d);
+    }
+    for (r = 4u; r < Rmax; r += 4u) {
+      q += 4 * D;
+      const uint4 a = load16<NT>(q);
+      const uint4 b = load16<NT>(q + D);
+      const uint4 c = load16<NT>(q + 2 * D);
+      const uint4 d = load16<NT>(q + 3 * D);
+      fold_plain(a);
+      fold_plain(b);
+      fold_plain(c);
+      fold_plain(d);
+    }
+  }
+  if (r == 0u && Rmax) {
+    // General shape.  For one buffer only its first row (leading bytes outside the message, and the
+    // initial register in message bytes 0..3) and its last row (trailing bytes outside) need the
+    // trimming of fold_checked; buffers end together, so the last row is row Rmax-1 for all of them,
+    // and a buffer's first row is row Rmax-R.  Rows [head_end, tail_begin) are whole for every buffer
+    // of the wave and are folded without trimming.
+    // (a buffer that starts in the last three bytes of a row has part of message bytes 0..3, which
+    // carry the initial register, in its second row too)
+    uint32_t fmax = live ? Rmax - R + (a0 > (uint32_t)(D - 4) ? 1u : 0u) : 0u;
+#pragma unroll
+    for (int o = 32; o >= G; o >>= 1) {
+      const uint32_t other = __shfl_xor(fmax, o);
+      fmax = other > fmax ? other : fmax;
+    }
+    fmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)fmax);
+    const uint32_t head_end = fmax + 1u < Rmax ? fmax + 1u : Rmax;
+    const uint32_t tail_begin = Rmax - 1u > head_end ? Rmax - 1u : head_end;
+    // Every burst issues its (up to) four row loads together - a load is skipped by lanes whose column
+    // lies outside the message - and then folds them in order, trimmed or plain by the row's class.
+    for (; r < Rmax; r += 4u) {
+      const uint32_t cnt = Rmax - r;  // rows in this burst if fewer than four
+      const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+      if (r >= head_end && r + 4u <= tail_begin) {
+        // four rows that are whole for every buffer of the wave that is walked at all: no per-row checks
+        uint4 a = z, b = z, c = z, d = z;
+        if (live) {
+          const uint8_t* q = ptr + (m0 + (int)(r * D));
+          a = load16<NT>(q);
+          b = load16<NT>(q + D);
+          c = load16<NT>(q + 2 * D);
+          d = load16<NT>(q + 3 * D);
+        }
+        fold_plain(a);
+        fold_plain(b);
+        fold_plain(c);
+        fold_plain(d);
+      } else {
+        // When the trailer is stored into the image behind the buffer, the burst that holds the last row
+        // is loaded with the default cache policy: the line the store goes to is then still in the cache,
+        // and the store does not have to fetch it again.
+        const bool keep = keep_tail && r + 4u >= Rmax;
+        const uint4 a = load_checked(r, keep);
+        const uint4 b = cnt > 1u ? load_checked(r + 1u, keep) : z;
+        const uint4 c = cnt > 2u ? load_checked(r + 2u, keep) : z;
+        const uint4 d = cnt > 3u ? load_checked(r + 3u, keep) : z;
+        if (r >= head_end && r < tail_begin) fold_plain(a); else fold_checked(a, r);
+        if (cnt > 1u) {
+          if (r + 1u >= head_end && r + 1u < tail_begin) fold_plain(b); else fold_checked(b, r + 1u);
+        }
+        if (cnt > 2u) {
+          if (r + 2u >= head_end && r + 2u < tail_begin) fold_plain(c); else fold_checked(c, r + 2u);
+        }
+        if (cnt > 3u) {
+          if (r + 3u >= head_end && r + 3u < tail_begin) fold_plain(d); else fold_checked(d, r + 3u);
+        }
+      }
+    }
+  }
+
+  // Column states -> one value per lane (bytes j*16 .. j*16+15 of the last row).
+  uint32_t u = fold_aux(aux, s0) ^ s1;
+  u = fold_aux(aux, u) ^ s2;
+  u = fold_aux(aux, u) ^ s3;
+  // Lanes -> lane G-1: at step d lanes [G-2d, G-d) hand Z_{16d}(u) to [G-d, G).
+#pragma unroll
+  for (int st = LOG2G; st >= 1; --st) {
+    const int dist = 1 << (st - 1);
+    const uint32_t t = fold_aux(aux + st * 1024, u);
+    u ^= __shfl_up(t, dist, G);
+  }
+
+  // The last dword still owes its own four bytes; then the trailing zeros are taken back out:
+  // r * x^(-8 tpad).  With UL lanes the 32 shift-and-xor steps are split: lane l takes the bits
+  // [32 l / UL, 32 (l+1) / UL) of r (counted from x^0) against x^(-8 tpad) * x^(32 l / UL) from the table.
+  uint32_t rfin = fold_aux(aux, u);  // meaningful on the group's last lane
+  if (UL == 1) {
+    if (live && tpad && j == G - 1) rfin = gf2_mulmod_dev(rfin, aux[(1 + LOG2G) * 1024 + tpad]);
+  } else if (__any(live && tpad != 0u)) {
+    const uint32_t rr = __shfl(rfin, lane | (G - 1));
+    const int l = j & (UL - 1);
+    uint32_t b = aux[(1 + LOG2G) * 1024 + tpad * UL + l];
+    uint32_t part = 0;
+#pragma unroll
+    for (int k = 0; k < 32 / UL; ++k) {
+      part ^= ((rr >> (31 - (32 / UL) * l - k)) & 1u) ? b : 0u;
+      b = (b >> 1) ^ ((b & 1u) ? 0x82f63b78u : 0u);
+    }
+#pragma unroll
+    for (int o = 1; o < UL; o <<= 1) part ^= __shfl_xor(part, o);
+    if (tpad) rfin = part;
+  }
+  uint32_t reg = rfin;
+  if (valid && !live && j == G - 1) {
+    reg = r0;
+    const uint32_t* T0 = aux + 768;  // one-byte step table
+    for (uint32_t k = 0; k < len; ++k) reg = T0[(reg ^ ptr[k]) & 0xffu] ^ (reg >> 8);
+  }
+  return reg;
 }
 
 template <bool SEG> struct SegArgs { typedef NoLongArgs type; };
@@ -102,13 +350,8 @@ __device__ __forceinline__ void seg_arrive(uint32_t* line, uint32_t value, uint3
 // SEG: the items are segments of long buffers described by `la` (tcrc_long.hip); otherwise `la` is empty.
 template <int G, bool NT, bool SEG>
 __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p, typename SegArgs<SEG>::type la) {
-  constexpr int D = 16 * G;
-  constexpr int LOG2G = Geo<G>::kLog2;
   constexpr int GPW = 64 / G;  // groups (buffers) per wave
-  // lanes of a group that share the un-shift multiplication (a whole wave per buffer keeps it on one lane:
-  // its table would not fit next to the others, and its buffers are long enough not to care)
-  constexpr int UL = G <= 16 ? 4 : 1;
-  constexpr int kAuxDwords = (1 + LOG2G) * 1024 + D * UL;  // reduction sets, then x^(-8t) * x^(32 l / UL) for t < D, l < UL
+  constexpr int kAuxDwords = AuxDwords<G>::value;
   __shared__ uint32_t lds[kMainDwords + kAuxDwords];
   // SEG: segments before every buffer of the launch, and the descriptors that came in the kernel arguments
   __shared__ uint32_t seg_first_lds[SEG ? kLongLdsBuffers + 1 : 1];
@@ -116,7 +359,9 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p, typename 
 
   const int tid = threadIdx.x;
   if (p.n_dev && *p.n_dev == 0) return;  // an empty list (uniform over the grid): nothing to set up
-  for (int i = tid; i < kMainDwords; i += kThreads) lds[i] = p.tab_main[i >> 5];
+  // dword i of the main set: pair i / 16384, entry (i / 64) mod 256, table of the pair (i / 32) mod 2
+  for (int i = tid; i < kMainDwords; i += kThreads)
+    lds[i] = p.tab_main[((i >> 14) * 2 + ((i >> 5) & 1)) * 256 + ((i >> 6) & 255)];
   for (int i = tid; i < kAuxDwords; i += kThreads) lds[kMainDwords + i] = p.tab_aux[i];
   if constexpr (SEG) {
     if (la.seg_first) {
@@ -139,7 +384,7 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p, typename 
   const int lane = tid & 63;
   const int j = lane & (G - 1);
   const int grp = lane / G;
-  const uint32_t* A = lds + (lane & 31);
+  const uint32_t LB = (uint32_t)(lane & 31) * 4u | 0x10000u;
   const uint32_t* aux = lds + kMainDwords;
   // rounds are dealt to workgroups first, then to the waves of a workgroup, so that a small
   // batch still spreads over all CUs
@@ -151,7 +396,6 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p, typename 
     n = nd < n ? nd : n;
   }
   const uint64_t nrounds = (n + GPW - 1) / GPW;
-  const bool wal_items = (p.flags & kFlagWalItems) != 0;
 
   // the descriptor of the next round is fetched while the current round runs
   tcrc_desc d_next = {0, 0, 0};
@@ -161,7 +405,7 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p, typename 
     const uint64_t buf = round * GPW + grp;
     const bool valid = buf < n;
     uint64_t off = 0;
-    uint32_t len = 0, init = 0, item_index = 0;
+    uint32_t len = 0, init = 0;
     bool oversize = false;
     const tcrc_desc dsc = d_next;
     if (p.desc) {
@@ -207,10 +451,6 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p, typename 
           len = 0;
           oversize = true;
         }
-        if (wal_items) {
-          item_index = init;  // record index inside its 32 KiB block
-          init = 0;
-        }
       } else {
         off = buf * p.stride;
         len = p.block_len;
@@ -227,224 +467,14 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p, typename 
         __builtin_memcpy(&stored, e, 4);  // one unaligned dword load
       }
     }
-    const uint32_t r0 = ~init;
-    const bool live = valid && len >= 16;  // shorter messages take the byte path at the end
-    const uint32_t elen = live ? len : 0u;
     const uint8_t* ptr = p.base + off;
-    // Rows are aligned to D-byte ADDRESS boundaries, so every 16-byte load is aligned and every
-    // row of a buffer is whole cache lines.  The bytes of the first row before the message and of
-    // the last row after it are read (same lines as message bytes) and masked to zero: leading
-    // zeros leave a CRC remainder unchanged, the `tpad` trailing ones are undone after the
-    // reduction by one multiplication with x^(-8 tpad).
-    const uint32_t a0 = live ? (uint32_t)((uintptr_t)ptr & (uintptr_t)(D - 1)) : 0u;
-    const uint32_t span = a0 + elen;
-    const uint32_t R = (span + D - 1) / D;
-    const uint32_t tpad = R * D - span;
-    uint32_t Rmax = R;
-#pragma unroll
-    for (int o = 32; o >= G; o >>= 1) {
-      const uint32_t other = __shfl_xor(Rmax, o);
-      Rmax = other > Rmax ? other : Rmax;
-    }
-    // the same in every lane now: kept in a scalar register, so that the row loops and the row classes
-    // below cost scalar instructions
-    Rmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)Rmax);
-    // A buffer with fewer rows than the longest of its wave starts later, so that all end together.
-    // message offset of this lane's column in row r is m0 + r*D
-    const int m0 = 16 * j - (int)a0 - (int)((Rmax - R) * D);
-    uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-
-    auto fold_plain = [&](const uint4& v) {
-      s0 = fold_main(A, s0) ^ v.x;
-      s1 = fold_main(A, s1) ^ v.y;
-      s2 = fold_main(A, s2) ^ v.z;
-      s3 = fold_main(A, s3) ^ v.w;
-    };
-    // A column that may stick out of the message at either end or hold some of its first four
-    // bytes (which carry the initial register): loaded only if it overlaps the message ...
-    auto load_checked = [&](uint32_t r, bool keep) -> uint4 {
-      const int m = m0 + (int)(r * D);
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (live && m > -16 && m < (int)elen) v = (NT && !keep) ? load16<true>(ptr + m) : load16<false>(ptr + m);
-      return v;
-    };
-    // ... and trimmed to the message, with the initial register folded into message bytes 0..3.
-    auto fold_checked = [&](uint4 v, uint32_t r) {
-      const int m = m0 + (int)(r * D);
-      if (live && m > -16 && m < (int)elen && (m < 4 || m + 16 > (int)elen)) {
-        unsigned long long lo = ((unsigned long long)v.y << 32) | v.x;
-        unsigned long long hi = ((unsigned long long)v.w << 32) | v.z;
-        if (m < 0) {  // bytes [0, -m) precede the message
-          const uint32_t k = (uint32_t)(-m);
-          if (k >= 8u) {
-            lo = 0;
-            hi &= ~0ull << (8u * (k - 8u));
-          } else {
-            lo &= ~0ull << (8u * k);
-          }
-        }
-        if (m + 16 > (int)elen) {  // only the first `keep` bytes belong to the message
-          const uint32_t keep = elen - (uint32_t)m;
-          if (keep <= 8u) {
-            hi = 0;
-            if (keep < 8u) lo &= (1ull << (8u * keep)) - 1ull;
-          } else {
-            hi &= (1ull << (8u * (keep - 8u))) - 1ull;
-          }
-        }
-        if (m < 4) {  // message bytes 0..3 sit at column bytes -m .. -m+3
-          if (m >= 0) {
-            lo ^= (unsigned long long)(r0 >> (8 * m));
-          } else {
-            const uint32_t k = (uint32_t)(-m);
-            if (k < 8u) {
-              lo ^= (unsigned long long)r0 << (8u * k);
-              if (k > 4u) hi ^= (unsigned long long)(r0 >> (64u - 8u * k));
-            } else {
-              hi ^= (unsigned long long)r0 << (8u * (k - 8u));
-            }
-          }
-        }
-        v = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
-      }
-      fold_plain(v);
-    };
-    // Rows go in bursts of four: four 16-byte loads per lane are issued back to back (512
-    // contiguous bytes per buffer), then folded in order as they arrive.  Bursts without overlap
-    // inside a wave measured faster than keeping loads in flight across the folds; the other
-    // waves of the CU cover the latency.  The Rmax mod 4 odd rows come first, one burst.
-    uint32_t r = 0;
-    // The common shape - every buffer of the wave starts and ends on a row boundary and has the
-    // same number of rows, a multiple of four - needs no per-group checks at all: only lane 0 of
-    // each group folds the initial register into its first dword.
-    if ((Rmax & 3u) == 0u && __all(live && a0 == 0u && tpad == 0u && R == Rmax)) {
-      const uint8_t* q = ptr + 16 * j;
-      {
-        uint4 a = load16<NT>(q);
-        const uint4 b = load16<NT>(q + D);
-        const uint4 c = load16<NT>(q + 2 * D);
-        const uint4 d = load16<NT>(q + 3 * D);
-        if (j == 0) a.x ^= r0;
-        fold_plain(a);
-        fold_plain(b);
-        fold_plain(c);
-        fold_plain(d);
-      }
-      for (r = 4u; r < Rmax; r += 4u) {
-        q += 4 * D;
-        const uint4 a = load16<NT>(q);
-        const uint4 b = load16<NT>(q + D);
-        const uint4 c = load16<NT>(q + 2 * D);
-        const uint4 d = load16<NT>(q + 3 * D);
-        fold_plain(a);
-        fold_plain(b);
-        fold_plain(c);
-        fold_plain(d);
-      }
-    }
-    if (r == 0u && Rmax) {
-      // General shape.  For one buffer only its first row (leading bytes outside the message, and the
-      // initial register in message bytes 0..3) and its last row (trailing bytes outside) need the
-      // trimming of fold_checked; buffers end together, so the last row is row Rmax-1 for all of them,
-      // and a buffer's first row is row Rmax-R.  Rows [head_end, tail_begin) are whole for every buffer
-      // of the wave and are folded without trimming.
-      // (a buffer that starts in the last three bytes of a row has part of message bytes 0..3, which
-      // carry the initial register, in its second row too)
-      uint32_t fmax = live ? Rmax - R + (a0 > (uint32_t)(D - 4) ? 1u : 0u) : 0u;
-#pragma unroll
-      for (int o = 32; o >= G; o >>= 1) {
-        const uint32_t other = __shfl_xor(fmax, o);
-        fmax = other > fmax ? other : fmax;
-      }
-      fmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)fmax);
-      const uint32_t head_end = fmax + 1u < Rmax ? fmax + 1u : Rmax;
-      const uint32_t tail_begin = Rmax - 1u > head_end ? Rmax - 1u : head_end;
-      // Every burst issues its (up to) four row loads together - a load is skipped by lanes whose column
-      // lies outside the message - and then folds them in order, trimmed or plain by the row's class.
-      for (; r < Rmax; r += 4u) {
-        const uint32_t cnt = Rmax - r;  // rows in this burst if fewer than four
-        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-        if (r >= head_end && r + 4u <= tail_begin) {
-          // four rows that are whole for every buffer of the wave that is walked at all: no per-row checks
-          uint4 a = z, b = z, c = z, d = z;
-          if (live) {
-            const uint8_t* q = ptr + (m0 + (int)(r * D));
-            a = load16<NT>(q);
-            b = load16<NT>(q + D);
-            c = load16<NT>(q + 2 * D);
-            d = load16<NT>(q + 3 * D);
-          }
-          fold_plain(a);
-          fold_plain(b);
-          fold_plain(c);
-          fold_plain(d);
-        } else {
-          // When the trailer is stored into the image behind the buffer, the burst that holds the last row
-          // is loaded with the default cache policy: the line the store goes to is then still in the cache,
-          // and the store does not have to fetch it again.
-          const bool keep = (p.flags & TCRC_F_STORE_AFTER) && r + 4u >= Rmax;
-          const uint4 a = load_checked(r, keep);
-          const uint4 b = cnt > 1u ? load_checked(r + 1u, keep) : z;
-          const uint4 c = cnt > 2u ? load_checked(r + 2u, keep) : z;
-          const uint4 d = cnt > 3u ? load_checked(r + 3u, keep) : z;
-          if (r >= head_end && r < tail_begin) fold_plain(a); else fold_checked(a, r);
-          if (cnt > 1u) {
-            if (r + 1u >= head_end && r + 1u < tail_begin) fold_plain(b); else fold_checked(b, r + 1u);
-          }
-          if (cnt > 2u) {
-            if (r + 2u >= head_end && r + 2u < tail_begin) fold_plain(c); else fold_checked(c, r + 2u);
-          }
-          if (cnt > 3u) {
-            if (r + 3u >= head_end && r + 3u < tail_begin) fold_plain(d); else fold_checked(d, r + 3u);
-          }
-        }
-      }
-    }
-
-    // Column states -> one value per lane (bytes j*16 .. j*16+15 of the last row).
-    uint32_t u = fold_aux(aux, s0) ^ s1;
-    u = fold_aux(aux, u) ^ s2;
-    u = fold_aux(aux, u) ^ s3;
-    // Lanes -> lane G-1: at step d lanes [G-2d, G-d) hand Z_{16d}(u) to [G-d, G).
-#pragma unroll
-    for (int st = LOG2G; st >= 1; --st) {
-      const int dist = 1 << (st - 1);
-      const uint32_t t = fold_aux(aux + st * 1024, u);
-      u ^= __shfl_up(t, dist, G);
-    }
-
-    // The last dword still owes its own four bytes; then the trailing zeros are taken back out:
-    // r * x^(-8 tpad).  With UL lanes the 32 shift-and-xor steps are split: lane l takes the bits
-    // [32 l / UL, 32 (l+1) / UL) of r (counted from x^0) against x^(-8 tpad) * x^(32 l / UL) from the table.
-    uint32_t rfin = fold_aux(aux, u);  // meaningful on the group's last lane
-    if (UL == 1) {
-      if (live && tpad && j == G - 1) rfin = gf2_mulmod_dev(rfin, aux[(1 + LOG2G) * 1024 + tpad]);
-    } else if (__any(live && tpad != 0u)) {
-      const uint32_t rr = __shfl(rfin, lane | (G - 1));
-      const int l = j & (UL - 1);
-      uint32_t b = aux[(1 + LOG2G) * 1024 + tpad * UL + l];
-      uint32_t part = 0;
-#pragma unroll
-      for (int k = 0; k < 32 / UL; ++k) {
-        part ^= ((rr >> (31 - (32 / UL) * l - k)) & 1u) ? b : 0u;
-        b = (b >> 1) ^ ((b & 1u) ? 0x82f63b78u : 0u);
-      }
-#pragma unroll
-      for (int o = 1; o < UL; o <<= 1) part ^= __shfl_xor(part, o);
-      if (tpad) rfin = part;
-    }
+    const uint32_t core = span_remainder<G, NT>(lds, LB, lane, ptr, len, init, valid,
+                                                (p.flags & TCRC_F_STORE_AFTER) != 0);
 
     uint32_t seg_value = 0;
     bool seg_have = false;
     if (valid && j == G - 1) {
-      uint32_t reg;
-      if (live) {
-        reg = rfin;
-      } else {
-        reg = r0;
-        const uint32_t* T0 = aux + 768;  // one-byte step table
-        for (uint32_t k = 0; k < len; ++k) reg = T0[(reg ^ ptr[k]) & 0xffu] ^ (reg >> 8);
-      }
+      uint32_t reg = core;
       int sfx = p.uniform_suffix;
       if (p.suffix) sfx = p.suffix[buf];
       if (sfx >= 0) reg = aux[768u + ((reg ^ (uint32_t)sfx) & 0xffu)] ^ (reg >> 8);
@@ -478,14 +508,7 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p, typename 
         if (p.ok) p.ok[buf] = good ? 1 : 0;
         if (!good) {
           atomicAdd(&p.counts[TCRC_CNT_MISMATCH], 1ull);
-          if (wal_items) {
-            // descriptors are in no particular order: report the first bad 32 KiB block instead
-            const uint32_t blk = p.item_block[buf];
-            atomicMin(&p.counts[TCRC_CNT_FIRST_BAD], (unsigned long long)(p.wal_block_base + blk));
-            atomicMin(&p.wal_blocks[blk].first_bad, item_index);
-          } else {
-            atomicMin(&p.counts[TCRC_CNT_FIRST_BAD], (unsigned long long)buf);
-          }
+          atomicMin(&p.counts[TCRC_CNT_FIRST_BAD], (unsigned long long)buf);
         }
       }
     }
@@ -509,6 +532,231 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p, typename 
     }
   }
   if (p.verify && blockIdx.x == 0 && tid == 0) atomicAdd(&p.counts[TCRC_CNT_CHECKED], (unsigned long long)n);
+}
+
+// ---- log scan --------------------------------------------------------------------------------------------
+// One launch verifies a slice of a log image the way log::Reader::ReadPhysicalRecord does block by block
+// (db/log_reader.cc:314-406).  A workgroup owns a contiguous run of 32 KiB blocks.  Its wave 0 walks the
+// record headers - every lane one block, the structural checks of db/log_reader.cc:317-384 - and appends one
+// 8-byte entry per checksummed span to a list in LDS; all sixteen waves (wave 0 too, once it has filled the
+// next list) take rounds of eight entries from the list and checksum them with eight lanes per entry.  Two
+// lists alternate, so the walk of the next blocks runs beside the checksums of the current ones.
+// A span longer than kWalChunk bytes (a fragment can be 32 KiB) is cut from its end into up to eight chunks
+// that sit side by side in one round (several such spans share a round when they fit): chunk remainders are
+// multiplied by x^(8 * bytes behind them) and XORed towards the span's first chunk with shuffles, so no span
+// keeps a lane group busy for more than 4 KiB.
+// Per block the kernel writes (n_records, first_bad, end_offset, end_code); the reference drops the rest of a
+// block at its first bad checksum (db/log_reader.cc:391-397), so that is all its policy code needs.
+constexpr int kWalListRounds = 96;                       // rounds of 8 entries one list holds
+constexpr int kWalListEntries = kWalListRounds * 8;      // 768 entries, 6 KiB
+constexpr uint32_t kWalFirstFillRounds = 24;             // the first list is kept short so that the checksums start early
+// entry: x = block (20 bits) | chunks behind this one << 20 (3 bits) | first chunk of its span << 23 | valid << 24
+//        y = start inside the block (15 bits) | length << 15
+constexpr uint32_t kWalEntryFirst = 1u << 23, kWalEntryValid = 1u << 24;
+
+// lanes below this one whose bit is set in `mask`
+__device__ __forceinline__ uint32_t lanes_below(unsigned long long mask) {
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+template <bool NT>
+__global__ __launch_bounds__(kThreads) void k_wal_fused(WalScanParams p) {
+  constexpr int G = 8;
+  constexpr int kAuxDwords = AuxDwords<G>::value;
+  __shared__ uint32_t lds[kMainDwords + kAuxDwords];
+  __shared__ uint2 list[2][kWalListEntries];
+  // per list: [0] rounds at the front (eight spans of up to kWalChunk bytes each), [1] rounds at the back (the
+  // chunks of longer spans), [2] next round to hand out; then the chunk powers
+  __shared__ uint32_t ctl[2][4];
+  __shared__ uint32_t pow_chunk[8];
+
+  const int tid = threadIdx.x;
+  for (int i = tid; i < kMainDwords; i += kThreads)
+    lds[i] = p.tab_main[((i >> 14) * 2 + ((i >> 5) & 1)) * 256 + ((i >> 6) & 255)];
+  for (int i = tid; i < kAuxDwords; i += kThreads) lds[kMainDwords + i] = p.tab_aux[i];
+  if (tid == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) pow_chunk[i] = p.pow_chunk[i];
+  }
+
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int j = lane & (G - 1);
+  const int grp = lane / G;
+  const uint32_t LB = (uint32_t)(lane & 31) * 4u | 0x10000u;
+
+  // this workgroup's run of blocks
+  const uint32_t b_lo = (uint32_t)(((uint64_t)p.nblocks * blockIdx.x) / gridDim.x);
+  const uint32_t b_hi = (uint32_t)(((uint64_t)p.nblocks * (blockIdx.x + 1)) / gridDim.x);
+
+  // walker state (wave 0): every lane walks one block at a time
+  uint32_t w_next = b_lo;  // next block to hand to an idle lane (the same in every lane)
+  uint32_t w_blk = 0, w_pos = 0, w_k = 0, w_records = 0;
+  bool w_active = false;
+
+  // Fills list L with up to cap_rounds rounds; leaves its counts in ctl[L].
+  auto fill = [&](int L, uint32_t cap_rounds) {
+    uint32_t front = 0, back = 0;  // entries at the front, rounds opened at the back
+    uint32_t bfill = 8;            // entries used in the newest round at the back
+    for (;;) {
+      const unsigned long long idle = __ballot(!w_active);
+      if (idle && w_next < b_hi) {
+        const uint32_t nb = w_next + lanes_below(idle);
+        if (!w_active && nb < b_hi) {
+          w_active = true;
+          w_blk = nb;
+          w_pos = 0;
+          w_k = 0;
+          p.blocks[nb].first_bad = 0xffffffffu;  // lowered by whoever finds a bad checksum in the block
+        }
+        const uint32_t handed = w_next + (uint32_t)__popcll(idle);
+        w_next = handed < b_hi ? handed : b_hi;
+      }
+      if (!__any(w_active)) break;  // the run is exhausted
+      const uint64_t base = (uint64_t)w_blk * kLogBlockBytes;
+      const uint64_t end = base + kLogBlockBytes < p.size ? base + kLogBlockBytes : p.size;
+      const bool last = p.tail && end == p.size;
+      uint32_t hs = 0, len = 0, code = 0;
+      bool ok = false;
+      if (w_active) ok = wal_step(p.img, base + w_pos, end, last, p.log_number, &hs, &len, &code);
+      const uint32_t span = len + hs - 6u;  // the CRC covers the type byte, the log number if any, and the payload
+      const bool is_long = ok && span > kWalChunk;
+      const bool is_short = ok && !is_long;
+      const unsigned long long m_short = __ballot(is_short), m_long = __ballot(is_long);
+      const uint32_t ns = (uint32_t)__popcll(m_short), nl = (uint32_t)__popcll(m_long);
+      // full: this step is taken again when the list is filled the next time.  An empty list takes any step
+      // (at most 64 rounds, the list holds 96), or a short first list could never be started.
+      if (((front + ns + 7u) >> 3) + back + nl > cap_rounds && (front | back) != 0u) break;
+      if (w_active && !ok) {
+        tcrc_wal_block* b = p.blocks + w_blk;
+        b->n_records = w_k;
+        b->end_offset = w_pos;
+        b->end_code = code;
+        w_records += w_k;
+        w_active = false;
+      }
+      const uint32_t start = w_pos + 6u;
+      if (is_short) {
+        list[L][front + lanes_below(m_short)] = make_uint2(w_blk | kWalEntryFirst | kWalEntryValid, start | (span << 15));
+      }
+      // Long spans, one lane after the other: the chunks of a span go into the newest round at the back if
+      // they still fit there, else into a fresh one (whose eight entries start out empty).
+      const uint32_t c = (span + kWalChunk - 1u) / kWalChunk;  // 2..8 chunks for a long span
+      for (unsigned long long m = m_long; m; m &= m - 1ull) {
+        const int src = __builtin_ctzll(m);
+        const uint32_t c_src = (uint32_t)__shfl((int)c, src);
+        if (bfill + c_src > 8u) {
+          ++back;
+          bfill = 0;
+          if (lane < 8) list[L][kWalListEntries - 8u * back + lane] = make_uint2(0u, 0u);
+        }
+        if (lane == src) {
+          uint2* e = &list[L][kWalListEntries - 8u * back + bfill];
+          const uint32_t stop = start + span;
+#pragma unroll
+          for (uint32_t i = 0; i < 8u; ++i) {
+            const uint32_t q = c - 1u - i;  // chunks behind chunk i
+            const uint32_t ce = stop - q * kWalChunk;
+            const uint32_t cs = i == 0u ? start : ce - kWalChunk;
+            if (i < c)
+              e[i] = make_uint2(w_blk | (q << 20) | (i == 0u ? kWalEntryFirst : 0u) | kWalEntryValid, cs | ((ce - cs) << 15));
+          }
+        }
+        bfill += c_src;
+      }
+      front += ns;
+      if (ok) {
+        w_pos += hs + len;
+        ++w_k;
+      }
+    }
+    // the front's last round is padded with empty entries
+    const uint32_t pad = (8u - (front & 7u)) & 7u;
+    if ((uint32_t)lane < pad) list[L][front + lane] = make_uint2(0u, 0u);
+    if (lane == 0) {
+      ctl[L][0] = (front + 7u) >> 3;
+      ctl[L][1] = back;
+      ctl[L][2] = 0u;
+    }
+  };
+
+  if (wave == 0) fill(0, kWalFirstFillRounds);
+  __syncthreads();
+  for (int L = 0;; L ^= 1) {
+    const uint32_t nf = ctl[L][0], nbk = ctl[L][1];
+    if (nf + nbk == 0u) break;  // nothing was left to walk
+    if (wave == 0) fill(L ^ 1, (uint32_t)kWalListRounds);
+    for (;;) {
+      uint32_t r = 0;
+      if (lane == 0) r = atomicAdd(&ctl[L][2], 1u);
+      r = (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
+      if (r >= nf + nbk) break;
+      const uint32_t at = r < nf ? r * 8u : (uint32_t)kWalListEntries - 8u * (r - nf + 1u);
+      const uint2 e = list[L][at + grp];
+      const bool valid = (e.x & kWalEntryValid) != 0u;
+      const bool first = (e.x & kWalEntryFirst) != 0u;
+      const uint32_t blk = e.x & 0xfffffu, q = (e.x >> 20) & 7u;
+      const uint32_t start = e.y & 0x7fffu, len = e.y >> 15;
+      const uint8_t* ptr = p.img + (uint64_t)blk * kLogBlockBytes + start;
+      // the stored value is fetched now so its latency hides behind the row loop
+      uint32_t stored = 0;
+      if (valid && first && j == G - 1) __builtin_memcpy(&stored, ptr - 6, 4);
+      const uint32_t core = span_remainder<G, NT>(lds, LB, lane, ptr, len, first ? 0u : 0xffffffffu, valid, false);
+      // chunk remainders, advanced through the bytes behind them, are XORed towards the span's first chunk:
+      // the group q chunks before a span's end takes in the q groups after it
+      uint32_t v = 0;
+      if (valid && j == G - 1) v = q ? gf2_mulmod_dev(core, pow_chunk[q]) : core;
+#pragma unroll
+      for (int d = 1; d < 8; d <<= 1) {
+        const uint32_t t = __shfl_down(v, (unsigned)(G * d));
+        if (q >= (uint32_t)d) v ^= t;
+      }
+      if (valid && first && j == G - 1) {
+        const uint32_t crc = ~v;
+        const uint32_t masked = ((crc >> 15) | (crc << 17)) + kMaskDelta;
+        if (stored != masked) {
+          atomicAdd(&p.counts[TCRC_CNT_MISMATCH], 1ull);
+          atomicMin(&p.counts[TCRC_CNT_FIRST_BAD], (unsigned long long)(p.block_base + blk));
+          // rare: the record's index inside its block is found by walking the block's headers again
+          const uint64_t base = (uint64_t)blk * kLogBlockBytes;
+          const uint64_t end = base + kLogBlockBytes < p.size ? base + kLogBlockBytes : p.size;
+          const bool last = p.tail && end == p.size;
+          uint32_t pos = 0, k = 0, hs = 0, ln = 0, code = 0;
+          while (pos + 6u < start && wal_step(p.img, base + pos, end, last, p.log_number, &hs, &ln, &code)) {
+            pos += hs + ln;
+            ++k;
+          }
+          atomicMin(&p.blocks[blk].first_bad, k);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (wave == 0) {
+    uint32_t total = w_records;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) total += __shfl_xor(total, o);
+    if (lane == 0) {
+      if (total) atomicAdd(&p.counts[TCRC_CNT_CHECKED], (unsigned long long)total);
+      if (p.records_host) {
+        // The launch's record count goes to the host without a copy command: workgroups add theirs to a device
+        // word and count themselves off; the last one takes the sum out (leaving both words zero for the next
+        // launch) and adds it to the caller's word in pinned host memory.  The additions are acknowledged
+        // before the count-off is issued (see seg_arrive).
+        (void)__hip_atomic_fetch_add(p.records_dev, (unsigned long long)total, __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long before =
+            __hip_atomic_fetch_add(p.records_dev + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (before + 1ull == (unsigned long long)gridDim.x) {
+          const unsigned long long sum =
+              __hip_atomic_exchange(p.records_dev, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          (void)__hip_atomic_exchange(p.records_dev + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          *p.records_host += sum;  // launches of one stream run one after the other
+        }
+      }
+    }
+  }
 }
 
 // Streaming-read probe: what a kernel that only loads (16 B per lane, whole lines, XOR-folded)
@@ -649,6 +897,25 @@ int run_segments(tcrc_ctx* ctx, BatchParams p, const LongArgs& la, void* stream)
   return TCRC_OK;
 }
 
+int run_wal_scan(tcrc_ctx* ctx, WalScanParams p, void* stream) {
+  if (!ctx) return fail(TCRC_ERR_INVALID, "null context");
+  if (p.nblocks == 0) return TCRC_OK;
+  if (p.nblocks > kWalMaxBlocks) return fail(TCRC_ERR_TOO_LARGE, "log slice above 32 GiB");
+  if (!p.img || !p.blocks || !p.counts) return fail(TCRC_ERR_INVALID, "null argument");
+  const int gi = geo_index(8);
+  p.tab_main = ctx->d_tab_main[gi];
+  p.tab_aux = ctx->d_tab_aux[gi];
+  for (uint32_t q = 0; q < 8; ++q) p.pow_chunk[q] = tcrc::gf2_xpow(8ull * kWalChunk * q);
+  const unsigned wgs = p.nblocks < (uint32_t)ctx->cus ? p.nblocks : (unsigned)ctx->cus;
+  hipStream_t s = (hipStream_t)stream;
+  if (ctx->nontemporal)
+    hipLaunchKernelGGL(k_wal_fused<true>, dim3(wgs), dim3(kThreads), 0, s, p);
+  else
+    hipLaunchKernelGGL(k_wal_fused<false>, dim3(wgs), dim3(kThreads), 0, s, p);
+  HIP_TRY(hipGetLastError());
+  return TCRC_OK;
+}
+
 int run_batch(tcrc_ctx* ctx, BatchParams p, void* stream) {
   if (!ctx) return fail(TCRC_ERR_INVALID, "null context");
   if (p.n == 0) return TCRC_OK;
@@ -657,10 +924,8 @@ int run_batch(tcrc_ctx* ctx, BatchParams p, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   int g = ctx->forced_g;  // set for experiments only
   if (g == 0 && p.lanes) g = p.lanes;  // the caller knows the shape of its spans (log scans)
-  // Log records are short (a fragment never exceeds 32 KiB, typical ones are a few KiB): four lanes
-  // per record halve the end-of-buffer reduction and measured ~9 % faster on 2 KiB records.
   if (g == 0) {
-    g = (p.flags & kFlagWalItems) ? 4 : 8;
+    g = 8;
     // A batch too small to give every wave of the chip eight buffers is latency-bound: spread each
     // buffer over more lanes instead (a whole wave per buffer when there are fewer buffers than waves).
     const uint64_t waves = (uint64_t)ctx->cus * 16;
@@ -758,7 +1023,7 @@ int tcrc_shutdown(tcrc_ctx* ctx) {
     if (ctx->d_tab_main[gi]) (void)hipFree(ctx->d_tab_main[gi]);
     if (ctx->d_tab_aux[gi]) (void)hipFree(ctx->d_tab_aux[gi]);
   }
-  for (tcrc_scratch* s : {&ctx->wal_items, &ctx->wal_item_block, &ctx->wal_misc, &ctx->wal_list_counts,
+  for (tcrc_scratch* s : {&ctx->wal_misc, &ctx->wal_list_counts,
                           &ctx->wal_list_first, &ctx->wal_list_temp, &ctx->wal_frags, &ctx->host_records,
                           &ctx->host_data, &ctx->host_desc, &ctx->host_out, &ctx->host_aux, &ctx->host_blocks,
                           &ctx->long_in, &ctx->long_acc})
@@ -768,6 +1033,7 @@ int tcrc_shutdown(tcrc_ctx* ctx) {
   if (ctx->stage_ring) (void)hipHostFree(ctx->stage_ring);
   if (ctx->zc) (void)hipHostFree(ctx->zc);
   if (ctx->long_pin) (void)hipHostFree(ctx->long_pin);
+  if (ctx->wal_pin) (void)hipHostFree(ctx->wal_pin);
   for (hipEvent_t ev : ctx->stage_done)
     if (ev) (void)hipEventDestroy(ev);
   delete ctx;

@@ -15,7 +15,6 @@
 namespace tcrc_internal {
 
 // internal flag bits (above the public TCRC_F_* ones)
-constexpr uint32_t kFlagWalItems = 0x100u;  // descriptors are log records: desc.init = index inside the 32 KiB block
 constexpr uint32_t kFlagSegments = 0x200u;  // the items are segments of longer buffers (LongArgs): results are shifted and XORed
 constexpr uint32_t kFlagStampBefore = 0x400u;  // the result is also stored as LE32 six bytes before the buffer (log header)
 
@@ -35,15 +34,56 @@ struct BatchParams {
   uint8_t* ok;
   unsigned long long* counts;
   const unsigned long long* n_dev;  // when set, the batch size is read from device memory (<= n)
-  const uint32_t* item_block;       // kFlagWalItems: 32 KiB block index of every item
-  tcrc_wal_block* wal_blocks;       // kFlagWalItems: per block result (first_bad is lowered on a mismatch)
-  uint64_t wal_block_base;          // kFlagWalItems: index of wal_blocks[0] in the whole image
   int lanes;                 // lanes per buffer to use (4, 8, 16, 64), 0 = let the engine choose
   const uint32_t* tab_main;  // 1024 dwords: Z_D set
   const uint32_t* tab_aux;   // (1+log2 G) sets of 1024 dwords: Z_4, Z_16, Z_32, ...
 };
 
 constexpr int kGeoCount = 4;
+
+constexpr uint32_t kLogBlockBytes = 32768;                     // db/log_format.h:37
+constexpr uint32_t kLogHeader = 7, kLogRecyclableHeader = 11;  // db/log_format.h:40,44
+
+// One header step of db/log_reader.cc:317-384.  Returns false when the walk of the block ends
+// (code says why); otherwise the record occupies [pos, pos + hs + len).
+__device__ __forceinline__ bool wal_step(const uint8_t* img, uint64_t pos, uint64_t end, bool last,
+                                         uint64_t log_number, uint32_t* hs_out, uint32_t* len_out,
+                                         uint32_t* code) {
+  const uint64_t remaining = end - pos;
+  if (remaining < kLogHeader) {
+    // a block trailer (zero padding), or at the very end of the file a truncated header
+    *code = remaining == 0 ? TCRC_WAL_END_CLEAN : (last ? TCRC_WAL_END_SHORT_AT_EOF : TCRC_WAL_END_TRAILER);
+    return false;
+  }
+  const uint8_t* h = img + pos;
+  const uint32_t len = (uint32_t)h[4] | ((uint32_t)h[5] << 8);
+  const uint32_t type = (uint32_t)(int)(signed char)h[6];  // the reference reads it through a char
+  uint32_t hs = kLogHeader;
+  if (type >= 5u && type <= 8u) {
+    hs = kLogRecyclableHeader;
+    if (remaining < kLogRecyclableHeader) {
+      *code = last ? TCRC_WAL_END_SHORT_AT_EOF : TCRC_WAL_END_TRAILER;
+      return false;
+    }
+    const uint32_t lognum = (uint32_t)h[7] | ((uint32_t)h[8] << 8) | ((uint32_t)h[9] << 16) | ((uint32_t)h[10] << 24);
+    if ((uint64_t)lognum != log_number) {
+      *code = TCRC_WAL_END_OLD_RECORD;
+      return false;
+    }
+  }
+  if ((uint64_t)hs + len > remaining) {
+    *code = last ? TCRC_WAL_END_BAD_LEN_AT_EOF : TCRC_WAL_END_BAD_LEN;
+    return false;
+  }
+  if (type == 0u && len == 0u) {
+    *code = TCRC_WAL_END_ZERO_RECORD;
+    return false;
+  }
+  *hs_out = hs;
+  *len_out = len;
+  return true;
+}
+
 
 // Long buffers: every buffer is cut from its END into segments of 2^seg_shift bytes (the first one may be
 // shorter); item s of the launch is segment s, and the kernel works out which buffer it belongs to and
@@ -69,6 +109,26 @@ struct LongArgs {
 };
 struct NoLongArgs {};
 
+// One launch of the log scan (tcrc_engine.hip: k_wal_fused) over a slice of a log image.
+constexpr uint32_t kWalChunk = 4096;        // spans longer than this are cut into chunks of this size (from their end)
+constexpr uint32_t kWalMaxBlocks = 1u << 20;  // 32 KiB blocks per launch (the entry format keeps 20 bits of block index)
+struct WalScanParams {
+  const uint8_t* img;          // first byte of the slice (a 32 KiB block boundary of the file)
+  uint64_t size;               // bytes in the slice (the last block may be short)
+  uint64_t log_number;
+  uint64_t block_base;         // index of the slice's first block in the whole file
+  uint32_t nblocks;
+  uint32_t tail;               // the slice ends where the file ends
+  tcrc_wal_block* blocks;      // [nblocks]
+  unsigned long long* counts;  // the caller's TCRC_CNT_* block (accumulated into)
+  unsigned long long* records_host;  // when not NULL: the launch's candidate records are added to this word of
+                                     // pinned host memory by the last workgroup to finish ...
+  unsigned long long* records_dev;   // ... which uses these two device words (zero before and after a launch)
+  uint32_t pow_chunk[8];       // x^(8 * kWalChunk * q) mod P
+  const uint32_t* tab_main;
+  const uint32_t* tab_aux;
+};
+
 // a * b mod P (register convention bit 31 = x^0), 32 shift-and-xor steps.
 __device__ __forceinline__ uint32_t gf2_mulmod_dev(uint32_t a, uint32_t b) {
   uint32_t prod = 0;
@@ -89,6 +149,8 @@ void build_tables(int G, std::vector<uint32_t>* main_tab, std::vector<uint32_t>*
 int run_batch(tcrc_ctx* ctx, BatchParams p, void* stream);
 // Launches it over the p.n segments that la describes (p.base, p.out and p.n are used).
 int run_segments(tcrc_ctx* ctx, BatchParams p, const LongArgs& la, void* stream);
+// Launches the fused log scan (tables and powers are filled in here).
+int run_wal_scan(tcrc_ctx* ctx, WalScanParams p, void* stream);
 // Per-device set-up of the long-buffer path at tcrc_init (the context's GPU is current): the power tables.
 int long_device_setup(tcrc_ctx* ctx);
 
@@ -139,7 +201,9 @@ struct tcrc_ctx {
   std::string description;
   // log-scan scratch (tcrc_wal.hip): one scan at a time per context
   std::mutex wal_mu;
-  tcrc_scratch wal_items, wal_item_block, wal_misc, wal_list_counts, wal_list_first, wal_list_temp, wal_frags;
+  tcrc_scratch wal_misc, wal_list_counts, wal_list_first, wal_list_temp, wal_frags;
+  uint64_t wal_calls = 0;  // picks the record-counter slot of a scan (guarded by wal_mu)
+  unsigned long long* wal_pin = nullptr;  // 32 words of pinned host memory the scan kernels report record counts into
   // host-pointer entry points (tcrc_host.hip): their own stream and staging, one call at a time
   std::mutex host_mu;
   hipStream_t host_stream = nullptr;
