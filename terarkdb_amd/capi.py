@@ -198,12 +198,13 @@ class Engine:
     def probe_read(self, base, nbytes, scratch, wgs_per_cu=1, stream=None):
         check(lib.tcrc_dev_probe_read(self.ctx, _dp(base), nbytes, _dp(scratch), wgs_per_cu, self._stream(stream)))
 
-    def wal_verify(self, img, size, log_number, blocks, counts, stream=None):
-        """blocks: int32/uint32 device tensor of shape [ceil(size/32768), 4]; returns the record count."""
+    def wal_verify(self, img, size, log_number, blocks, counts, stream=None, want_records=True):
+        """blocks: int32/uint32 device tensor of shape [ceil(size/32768), 4]; returns the record count (which
+        makes the call wait for the scan), or None with want_records=False (the call then only enqueues)."""
         n = C.c_uint64(0)
-        check(lib.tcrc_dev_wal_verify(self.ctx, _dp(img), size, log_number, _dp(blocks), _dp(counts), C.byref(n),
-                                      self._stream(stream)))
-        return n.value
+        check(lib.tcrc_dev_wal_verify(self.ctx, _dp(img), size, log_number, _dp(blocks), _dp(counts),
+                                      C.byref(n) if want_records else None, self._stream(stream)))
+        return n.value if want_records else None
 
     def wal_frame(self, src, offsets, lens, log_number, recycle, dst, block_offset=0, stream=None):
         """Frames the records src[offsets[i] : offsets[i] + lens[i]] into dst (both device uint8 tensors);

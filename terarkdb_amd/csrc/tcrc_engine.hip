@@ -96,7 +96,8 @@ __device__ __forceinline__ uint32_t fold_aux(const uint32_t* t, uint32_t c) {
 // register BEFORE the final inversion (and before any suffix byte), meaningful on the last lane of every
 // group whose `valid` is set; groups that are not valid walk nothing.  All 64 lanes of the wave must call it
 // together (the row count is agreed on with shuffles).  keep_tail: load the burst that holds the last row
-// with the default cache policy (something is about to be stored right behind the span).
+// with the default cache policy (something is about to be stored right behind the span).  safe: 4 KiB of
+// readable global memory that lane groups without rows load from where the others load rows.
 // reduction sets, then x^(-8t) * x^(32 l / UL) for t < D, l < UL
 template <int G> struct AuxDwords {
   static constexpr int value = (1 + Geo<G>::kLog2) * 1024 + 16 * G * (G <= 16 ? 4 : 1);
@@ -104,7 +105,8 @@ template <int G> struct AuxDwords {
 
 template <int G, bool NT>
 __device__ __forceinline__ uint32_t span_remainder(const uint32_t* lds, uint32_t LB, int lane, const uint8_t* ptr,
-                                                   uint32_t len, uint32_t init, bool valid, bool keep_tail) {
+                                                   uint32_t len, uint32_t init, bool valid, bool keep_tail,
+                                                   const uint8_t* safe) {
   constexpr int D = 16 * G;
   constexpr int LOG2G = Geo<G>::kLog2;
   // lanes of a group that share the un-shift multiplication (a whole wave per buffer keeps it on one lane:
@@ -243,46 +245,65 @@ __device__ __forceinline__ uint32_t span_remainder(const uint32_t* lds, uint32_t
     fmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)fmax);
     const uint32_t head_end = fmax + 1u < Rmax ? fmax + 1u : Rmax;
     const uint32_t tail_begin = Rmax - 1u > head_end ? Rmax - 1u : head_end;
-    // Every burst issues its (up to) four row loads together - a load is skipped by lanes whose column
-    // lies outside the message - and then folds them in order, trimmed or plain by the row's class.
-    for (; r < Rmax; r += 4u) {
-      const uint32_t cnt = Rmax - r;  // rows in this burst if fewer than four
-      const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-      if (r >= head_end && r + 4u <= tail_begin) {
-        // four rows that are whole for every buffer of the wave that is walked at all: no per-row checks
-        uint4 a = z, b = z, c = z, d = z;
-        if (live) {
-          const uint8_t* q = ptr + (m0 + (int)(r * D));
-          a = load16<NT>(q);
-          b = load16<NT>(q + D);
-          c = load16<NT>(q + 2 * D);
-          d = load16<NT>(q + 3 * D);
-        }
-        fold_plain(a);
-        fold_plain(b);
-        fold_plain(c);
-        fold_plain(d);
-      } else {
+    // Checked bursts: up to four row loads are issued together - a load is skipped by lanes whose column lies
+    // outside the message - and then folded in order, trimmed or plain by the row's class.
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    auto bursts = [&](uint32_t from, uint32_t to) {
+      for (uint32_t x = from; x < to; x += 4u) {
+        const uint32_t cnt = to - x;  // rows in this burst if fewer than four
         // When the trailer is stored into the image behind the buffer, the burst that holds the last row
         // is loaded with the default cache policy: the line the store goes to is then still in the cache,
         // and the store does not have to fetch it again.
-        const bool keep = keep_tail && r + 4u >= Rmax;
-        const uint4 a = load_checked(r, keep);
-        const uint4 b = cnt > 1u ? load_checked(r + 1u, keep) : z;
-        const uint4 c = cnt > 2u ? load_checked(r + 2u, keep) : z;
-        const uint4 d = cnt > 3u ? load_checked(r + 3u, keep) : z;
-        if (r >= head_end && r < tail_begin) fold_plain(a); else fold_checked(a, r);
+        const bool keep = keep_tail && x + 4u >= Rmax;
+        const uint4 a = load_checked(x, keep);
+        const uint4 b = cnt > 1u ? load_checked(x + 1u, keep) : z;
+        const uint4 c = cnt > 2u ? load_checked(x + 2u, keep) : z;
+        const uint4 d = cnt > 3u ? load_checked(x + 3u, keep) : z;
+        if (x >= head_end && x < tail_begin) fold_plain(a); else fold_checked(a, x);
         if (cnt > 1u) {
-          if (r + 1u >= head_end && r + 1u < tail_begin) fold_plain(b); else fold_checked(b, r + 1u);
+          if (x + 1u >= head_end && x + 1u < tail_begin) fold_plain(b); else fold_checked(b, x + 1u);
         }
         if (cnt > 2u) {
-          if (r + 2u >= head_end && r + 2u < tail_begin) fold_plain(c); else fold_checked(c, r + 2u);
+          if (x + 2u >= head_end && x + 2u < tail_begin) fold_plain(c); else fold_checked(c, x + 2u);
         }
         if (cnt > 3u) {
-          if (r + 3u >= head_end && r + 3u < tail_begin) fold_plain(d); else fold_checked(d, r + 3u);
+          if (x + 3u >= head_end && x + 3u < tail_begin) fold_plain(d); else fold_checked(d, x + 3u);
         }
       }
+    };
+    // The rows before head_end go in checked bursts.  Then the whole rows, as many of them as make a multiple
+    // of four, go through a window of four loads in flight: a row is folded and its register is at once given
+    // to the load of the row four further on, so the memory latency is paid once and not once per four rows
+    // (buffers of a few KiB are bound by that latency, not by bandwidth).  That loop has no branch in it -
+    // lane groups that walk nothing read a harmless address instead of being masked off - because only then
+    // does the compiler count the loads in flight instead of waiting for all of them.  What is left (up to
+    // three whole rows and the last row) is one more checked burst.
+    const uint32_t mid_end = head_end + ((tail_begin - head_end) & ~3u);
+    bursts(0u, head_end);
+    if (mid_end > head_end) {
+      const uint8_t* q = live ? ptr + (m0 + (int)(head_end * D)) : safe;
+      const uint32_t qstep = live ? 4u * D : 0u;
+      uint4 a = load16<NT>(q);
+      uint4 b = load16<NT>(q + D);
+      uint4 c = load16<NT>(q + 2 * D);
+      uint4 d = load16<NT>(q + 3 * D);
+      for (uint32_t x = head_end + 4u; x < mid_end; x += 4u) {
+        q += qstep;
+        fold_plain(a);
+        a = load16<NT>(q);
+        fold_plain(b);
+        b = load16<NT>(q + D);
+        fold_plain(c);
+        c = load16<NT>(q + 2 * D);
+        fold_plain(d);
+        d = load16<NT>(q + 3 * D);
+      }
+      fold_plain(a);
+      fold_plain(b);
+      fold_plain(c);
+      fold_plain(d);
     }
+    bursts(mid_end, Rmax);
   }
 
   // Column states -> one value per lane (bytes j*16 .. j*16+15 of the last row).
@@ -469,7 +490,7 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p, typename 
     }
     const uint8_t* ptr = p.base + off;
     const uint32_t core = span_remainder<G, NT>(lds, LB, lane, ptr, len, init, valid,
-                                                (p.flags & TCRC_F_STORE_AFTER) != 0);
+                                                (p.flags & TCRC_F_STORE_AFTER) != 0, (const uint8_t*)p.tab_main);
 
     uint32_t seg_value = 0;
     bool seg_have = false;
@@ -585,12 +606,19 @@ __global__ __launch_bounds__(kThreads) void k_wal_fused(WalScanParams p) {
   const int grp = lane / G;
   const uint32_t LB = (uint32_t)(lane & 31) * 4u | 0x10000u;
 
-  // this workgroup's run of blocks
-  const uint32_t b_lo = (uint32_t)(((uint64_t)p.nblocks * blockIdx.x) / gridDim.x);
-  const uint32_t b_hi = (uint32_t)(((uint64_t)p.nblocks * (blockIdx.x + 1)) / gridDim.x);
+  // This workgroup's blocks: the image is dealt out in chunks of 2^chunk_shift consecutive blocks, chunk c to
+  // workgroup c mod gridDim.x, so that at any time the workgroups read neighbouring pieces of the image.  The
+  // walker numbers its own blocks 0, 1, 2, ...: number v is block v mod 2^s of the workgroup's chunk v >> s.
+  const uint32_t cs = p.chunk_shift;
+  const uint32_t nchunks = (p.nblocks + (1u << cs) - 1u) >> cs;
+  const uint32_t my_chunks = nchunks > blockIdx.x ? (nchunks - blockIdx.x + gridDim.x - 1u) / gridDim.x : 0u;
+  const uint32_t b_hi = my_chunks << cs;  // numbers, not all of them blocks of the image (the last chunk may be short)
+  auto block_of = [&](uint32_t v) -> uint32_t {
+    return (((v >> cs) * gridDim.x + blockIdx.x) << cs) + (v & ((1u << cs) - 1u));
+  };
 
   // walker state (wave 0): every lane walks one block at a time
-  uint32_t w_next = b_lo;  // next block to hand to an idle lane (the same in every lane)
+  uint32_t w_next = 0;  // next number to hand to an idle lane (the same in every lane)
   uint32_t w_blk = 0, w_pos = 0, w_k = 0, w_records = 0;
   bool w_active = false;
 
@@ -601,8 +629,9 @@ __global__ __launch_bounds__(kThreads) void k_wal_fused(WalScanParams p) {
     for (;;) {
       const unsigned long long idle = __ballot(!w_active);
       if (idle && w_next < b_hi) {
-        const uint32_t nb = w_next + lanes_below(idle);
-        if (!w_active && nb < b_hi) {
+        const uint32_t nv = w_next + lanes_below(idle);
+        const uint32_t nb = block_of(nv);
+        if (!w_active && nv < b_hi && nb < p.nblocks) {
           w_active = true;
           w_blk = nb;
           w_pos = 0;
@@ -680,7 +709,7 @@ __global__ __launch_bounds__(kThreads) void k_wal_fused(WalScanParams p) {
     }
   };
 
-  if (wave == 0) fill(0, kWalFirstFillRounds);
+  if (wave == 0) fill(0, p.first_rounds);
   __syncthreads();
   for (int L = 0;; L ^= 1) {
     const uint32_t nf = ctl[L][0], nbk = ctl[L][1];
@@ -701,7 +730,8 @@ __global__ __launch_bounds__(kThreads) void k_wal_fused(WalScanParams p) {
       // the stored value is fetched now so its latency hides behind the row loop
       uint32_t stored = 0;
       if (valid && first && j == G - 1) __builtin_memcpy(&stored, ptr - 6, 4);
-      const uint32_t core = span_remainder<G, NT>(lds, LB, lane, ptr, len, first ? 0u : 0xffffffffu, valid, false);
+      const uint32_t core = span_remainder<G, NT>(lds, LB, lane, ptr, len, first ? 0u : 0xffffffffu, valid, false,
+                                                  (const uint8_t*)p.tab_main);
       // chunk remainders, advanced through the bytes behind them, are XORed towards the span's first chunk:
       // the group q chunks before a span's end takes in the q groups after it
       uint32_t v = 0;
@@ -906,6 +936,18 @@ int run_wal_scan(tcrc_ctx* ctx, WalScanParams p, void* stream) {
   p.tab_main = ctx->d_tab_main[gi];
   p.tab_aux = ctx->d_tab_aux[gi];
   for (uint32_t q = 0; q < 8; ++q) p.pow_chunk[q] = tcrc::gf2_xpow(8ull * kWalChunk * q);
+  p.first_rounds = kWalFirstFillRounds;
+  // chunks of up to 64 blocks (one per walker lane), at least two chunks per workgroup
+  p.chunk_shift = 6;
+  while (p.chunk_shift > 0 && (p.nblocks >> p.chunk_shift) < 2u * (uint32_t)ctx->cus) --p.chunk_shift;
+  if (const char* e = getenv("TCRC_WAL_CHUNK_SHIFT")) {  // experiments only
+    const int v = atoi(e);
+    if (v >= 0 && v <= 20) p.chunk_shift = (uint32_t)v;
+  }
+  if (const char* e = getenv("TCRC_WAL_FIRST_ROUNDS")) {  // experiments only
+    const int v = atoi(e);
+    if (v >= 1 && v <= kWalListRounds) p.first_rounds = (uint32_t)v;
+  }
   const unsigned wgs = p.nblocks < (uint32_t)ctx->cus ? p.nblocks : (unsigned)ctx->cus;
   hipStream_t s = (hipStream_t)stream;
   if (ctx->nontemporal)

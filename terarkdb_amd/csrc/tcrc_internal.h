@@ -119,6 +119,8 @@ struct WalScanParams {
   uint64_t block_base;         // index of the slice's first block in the whole file
   uint32_t nblocks;
   uint32_t tail;               // the slice ends where the file ends
+  uint32_t chunk_shift;        // log2 of the blocks per chunk dealt to a workgroup at a time
+  uint32_t first_rounds;       // rounds the first list is cut off at (the checksums start once it is filled)
   tcrc_wal_block* blocks;      // [nblocks]
   unsigned long long* counts;  // the caller's TCRC_CNT_* block (accumulated into)
   unsigned long long* records_host;  // when not NULL: the launch's candidate records are added to this word of
