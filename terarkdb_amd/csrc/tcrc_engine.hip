@@ -557,27 +557,48 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p, typename 
 
 // ---- log scan --------------------------------------------------------------------------------------------
 // One launch verifies a slice of a log image the way log::Reader::ReadPhysicalRecord does block by block
-// (db/log_reader.cc:314-406).  A workgroup owns a contiguous run of 32 KiB blocks.  Its wave 0 walks the
-// record headers - every lane one block, the structural checks of db/log_reader.cc:317-384 - and appends one
-// 8-byte entry per checksummed span to a list in LDS; all sixteen waves (wave 0 too, once it has filled the
-// next list) take rounds of eight entries from the list and checksum them with eight lanes per entry.  Two
-// lists alternate, so the walk of the next blocks runs beside the checksums of the current ones.
-// A span longer than kWalChunk bytes (a fragment can be 32 KiB) is cut from its end into up to eight chunks
-// that sit side by side in one round (several such spans share a round when they fit): chunk remainders are
-// multiplied by x^(8 * bytes behind them) and XORed towards the span's first chunk with shuffles, so no span
-// keeps a lane group busy for more than 4 KiB.
+// (db/log_reader.cc:314-406).  The image is dealt to the workgroups in chunks of consecutive 32 KiB blocks.
+// Wave 0 of a workgroup walks the record headers - every lane one block, the structural checks of
+// db/log_reader.cc:317-384 - and cuts every checksummed span, from its end, into pieces of at most kWalPiece
+// bytes; one 8-byte entry per piece goes to a list in LDS, densely packed.  All sixteen waves (wave 0 too,
+// once it has filled the next list) take rounds of eight entries from the list and checksum them with eight
+// lanes per entry.  Two lists alternate, so the walk of the next blocks runs beside the checksums of the
+// current ones.
+// A span of one piece is compared with its stored checksum right away.  The pieces of a longer span (a
+// fragment can be 32 KiB: sixteen pieces, checksummed by different waves at the same time) meet in a slot in
+// LDS: every piece's remainder is multiplied by x^(8 * bytes behind it), XORed into the slot and counted off;
+// whoever counts off last compares the sum with the stored checksum, which the first piece left in the slot.
 // Per block the kernel writes (n_records, first_bad, end_offset, end_code); the reference drops the rest of a
 // block at its first bad checksum (db/log_reader.cc:391-397), so that is all its policy code needs.
 constexpr int kWalListRounds = 96;                       // rounds of 8 entries one list holds
 constexpr int kWalListEntries = kWalListRounds * 8;      // 768 entries, 6 KiB
 constexpr uint32_t kWalFirstFillRounds = 24;             // the first list is kept short so that the checksums start early
-// entry: x = block (20 bits) | chunks behind this one << 20 (3 bits) | first chunk of its span << 23 | valid << 24
+constexpr int kWalSlots = 40;                            // spans of several pieces one list can hold
+// entry: x = block (19 bits) | pieces behind this one << 19 (5 bits) | first piece of its span << 24 | valid << 25 |
+//            slot << 26 (63: the span is this one piece)
 //        y = start inside the block (15 bits) | length << 15
-constexpr uint32_t kWalEntryFirst = 1u << 23, kWalEntryValid = 1u << 24;
+constexpr uint32_t kWalEntryFirst = 1u << 24, kWalEntryValid = 1u << 25, kWalNoSlot = 63u;
+struct WalSlot {
+  uint32_t acc;        // XOR of the pieces' shifted remainders so far
+  uint32_t remaining;  // pieces still to come
+  uint32_t stored;     // the span's stored checksum, left here by whoever checksums the first piece
+  uint32_t blk;        // where the span is: its block and the offset of its first byte in it
+  uint32_t start;
+};
 
 // lanes below this one whose bit is set in `mask`
 __device__ __forceinline__ uint32_t lanes_below(unsigned long long mask) {
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// Sum of v (below 32) over the lanes below this one: one ballot per bit of v and a count of the lower lanes in
+// it - scalar and cheap vector instructions only, where a scan with shuffles takes six trips through the LDS
+// crossbar (the walker's steps are a chain of dependent operations, so their latency is what counts).
+__device__ __forceinline__ uint32_t sum_below_5bit(uint32_t v) {
+  uint32_t sum = 0;
+#pragma unroll
+  for (int b = 0; b < 5; ++b) sum += lanes_below(__ballot((v >> b) & 1u)) << b;
+  return sum;
 }
 
 template <bool NT>
@@ -586,18 +607,24 @@ __global__ __launch_bounds__(kThreads) void k_wal_fused(WalScanParams p) {
   constexpr int kAuxDwords = AuxDwords<G>::value;
   __shared__ uint32_t lds[kMainDwords + kAuxDwords];
   __shared__ uint2 list[2][kWalListEntries];
-  // per list: [0] rounds at the front (eight spans of up to kWalChunk bytes each), [1] rounds at the back (the
-  // chunks of longer spans), [2] next round to hand out; then the chunk powers
-  __shared__ uint32_t ctl[2][4];
-  __shared__ uint32_t pow_chunk[8];
+  __shared__ WalSlot slots[2][kWalSlots];
+  __shared__ uint32_t ctl[2][2];  // per list: [0] rounds in it, [1] next round to hand out
+  __shared__ uint32_t pow_piece[16];
 
   const int tid = threadIdx.x;
+  // trace (development aid): wave 0 notes the time at [0] start, [1] first list filled, then per phase
+  // [2 + 3i] its start, [3 + 3i] next list filled, [4 + 3i] wave 0 out of rounds; [31] end
+  uint32_t t_at = 0;
+  auto stamp = [&](uint32_t at) {
+    if (p.trace && tid == 0 && at < 32u) p.trace[blockIdx.x * 32u + at] = wall_clock64();
+  };
+  stamp(0);
   for (int i = tid; i < kMainDwords; i += kThreads)
     lds[i] = p.tab_main[((i >> 14) * 2 + ((i >> 5) & 1)) * 256 + ((i >> 6) & 255)];
   for (int i = tid; i < kAuxDwords; i += kThreads) lds[kMainDwords + i] = p.tab_aux[i];
   if (tid == 0) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) pow_chunk[i] = p.pow_chunk[i];
+    for (int i = 0; i < 16; ++i) pow_piece[i] = p.pow_piece[i];
   }
 
   const int lane = tid & 63;
@@ -609,6 +636,9 @@ __global__ __launch_bounds__(kThreads) void k_wal_fused(WalScanParams p) {
   // This workgroup's blocks: the image is dealt out in chunks of 2^chunk_shift consecutive blocks, chunk c to
   // workgroup c mod gridDim.x, so that at any time the workgroups read neighbouring pieces of the image.  The
   // walker numbers its own blocks 0, 1, 2, ...: number v is block v mod 2^s of the workgroup's chunk v >> s.
+  // (Handing chunks out from a counter in device memory instead was tried: it changes nothing for a large
+  // image, whose scan is bound by the whole chip's memory system and not by the slowest workgroup, and for a
+  // small one the workgroups that start first take everything.)
   const uint32_t cs = p.chunk_shift;
   const uint32_t nchunks = (p.nblocks + (1u << cs) - 1u) >> cs;
   const uint32_t my_chunks = nchunks > blockIdx.x ? (nchunks - blockIdx.x + gridDim.x - 1u) / gridDim.x : 0u;
@@ -622,10 +652,10 @@ __global__ __launch_bounds__(kThreads) void k_wal_fused(WalScanParams p) {
   uint32_t w_blk = 0, w_pos = 0, w_k = 0, w_records = 0;
   bool w_active = false;
 
-  // Fills list L with up to cap_rounds rounds; leaves its counts in ctl[L].
+  // Fills list L with up to cap_rounds rounds; leaves its round count in ctl[L].
   auto fill = [&](int L, uint32_t cap_rounds) {
-    uint32_t front = 0, back = 0;  // entries at the front, rounds opened at the back
-    uint32_t bfill = 8;            // entries used in the newest round at the back
+    const uint32_t cap = cap_rounds * 8u;
+    uint32_t count = 0, used = 0;  // entries in the list, slots taken
     for (;;) {
       const unsigned long long idle = __ballot(!w_active);
       if (idle && w_next < b_hi) {
@@ -641,22 +671,14 @@ __global__ __launch_bounds__(kThreads) void k_wal_fused(WalScanParams p) {
         const uint32_t handed = w_next + (uint32_t)__popcll(idle);
         w_next = handed < b_hi ? handed : b_hi;
       }
-      if (!__any(w_active)) break;  // the run is exhausted
+      if (!__any(w_active)) break;  // nothing left to walk
       const uint64_t base = (uint64_t)w_blk * kLogBlockBytes;
       const uint64_t end = base + kLogBlockBytes < p.size ? base + kLogBlockBytes : p.size;
       const bool last = p.tail && end == p.size;
       uint32_t hs = 0, len = 0, code = 0;
       bool ok = false;
       if (w_active) ok = wal_step(p.img, base + w_pos, end, last, p.log_number, &hs, &len, &code);
-      const uint32_t span = len + hs - 6u;  // the CRC covers the type byte, the log number if any, and the payload
-      const bool is_long = ok && span > kWalChunk;
-      const bool is_short = ok && !is_long;
-      const unsigned long long m_short = __ballot(is_short), m_long = __ballot(is_long);
-      const uint32_t ns = (uint32_t)__popcll(m_short), nl = (uint32_t)__popcll(m_long);
-      // full: this step is taken again when the list is filled the next time.  An empty list takes any step
-      // (at most 64 rounds, the list holds 96), or a short first list could never be started.
-      if (((front + ns + 7u) >> 3) + back + nl > cap_rounds && (front | back) != 0u) break;
-      if (w_active && !ok) {
+      if (w_active && !ok) {  // the block's walk ends here: that needs no room in the list
         tcrc_wal_block* b = p.blocks + w_blk;
         b->n_records = w_k;
         b->end_offset = w_pos;
@@ -664,67 +686,83 @@ __global__ __launch_bounds__(kThreads) void k_wal_fused(WalScanParams p) {
         w_records += w_k;
         w_active = false;
       }
-      const uint32_t start = w_pos + 6u;
-      if (is_short) {
-        list[L][front + lanes_below(m_short)] = make_uint2(w_blk | kWalEntryFirst | kWalEntryValid, start | (span << 15));
-      }
-      // Long spans, one lane after the other: the chunks of a span go into the newest round at the back if
-      // they still fit there, else into a fresh one (whose eight entries start out empty).
-      const uint32_t c = (span + kWalChunk - 1u) / kWalChunk;  // 2..8 chunks for a long span
-      for (unsigned long long m = m_long; m; m &= m - 1ull) {
-        const int src = __builtin_ctzll(m);
-        const uint32_t c_src = (uint32_t)__shfl((int)c, src);
-        if (bfill + c_src > 8u) {
-          ++back;
-          bfill = 0;
-          if (lane < 8) list[L][kWalListEntries - 8u * back + lane] = make_uint2(0u, 0u);
+      // the CRC covers the type byte, the log number if any, and the payload
+      const uint32_t span = len + hs - 6u;
+      const uint32_t c = ok ? (span + kWalPiece - 1u) / kWalPiece : 0u;  // 1..16 pieces
+      const bool multi = c > 1u;
+      // Lanes take room in lane order; those that no longer fit (a list takes 96 rounds and 40 spans of several
+      // pieces) keep their record for the next list.  The lowest lane with a record always fits an empty list.
+      const uint32_t upto_e = sum_below_5bit(c) + c, upto_s = lanes_below(__ballot(multi)) + (multi ? 1u : 0u);
+      const bool fits = ok && count + upto_e <= cap && used + upto_s <= (uint32_t)kWalSlots;
+      if (fits) {
+        const uint32_t slot = multi ? used + upto_s - 1u : kWalNoSlot;
+        const uint32_t start = w_pos + 6u, stop = start + span;
+        uint2* e = &list[L][count + upto_e - c];
+        for (uint32_t i = 0; i < c; ++i) {
+          const uint32_t q = c - 1u - i;  // pieces behind piece i
+          const uint32_t pe = stop - q * kWalPiece;
+          const uint32_t ps = i == 0u ? start : pe - kWalPiece;
+          e[i] = make_uint2(w_blk | (q << 19) | (i == 0u ? kWalEntryFirst : 0u) | kWalEntryValid | (slot << 26),
+                            ps | ((pe - ps) << 15));
         }
-        if (lane == src) {
-          uint2* e = &list[L][kWalListEntries - 8u * back + bfill];
-          const uint32_t stop = start + span;
-#pragma unroll
-          for (uint32_t i = 0; i < 8u; ++i) {
-            const uint32_t q = c - 1u - i;  // chunks behind chunk i
-            const uint32_t ce = stop - q * kWalChunk;
-            const uint32_t cs = i == 0u ? start : ce - kWalChunk;
-            if (i < c)
-              e[i] = make_uint2(w_blk | (q << 20) | (i == 0u ? kWalEntryFirst : 0u) | kWalEntryValid, cs | ((ce - cs) << 15));
-          }
+        if (multi) {
+          slots[L][slot].acc = 0u;
+          slots[L][slot].remaining = c;
         }
-        bfill += c_src;
-      }
-      front += ns;
-      if (ok) {
         w_pos += hs + len;
         ++w_k;
       }
+      const unsigned long long m_fit = __ballot(fits);
+      if (m_fit) {
+        const int top = 63 - __builtin_clzll(m_fit);
+        count += (uint32_t)__shfl((int)upto_e, top);
+        used += (uint32_t)__shfl((int)upto_s, top);
+      }
+      if (__any(ok && !fits)) break;  // full
     }
-    // the front's last round is padded with empty entries
-    const uint32_t pad = (8u - (front & 7u)) & 7u;
-    if ((uint32_t)lane < pad) list[L][front + lane] = make_uint2(0u, 0u);
+    // the last round is padded with empty entries
+    const uint32_t pad = (8u - (count & 7u)) & 7u;
+    if ((uint32_t)lane < pad) list[L][count + lane] = make_uint2(0u, 0u);
     if (lane == 0) {
-      ctl[L][0] = (front + 7u) >> 3;
-      ctl[L][1] = back;
-      ctl[L][2] = 0u;
+      ctl[L][0] = (count + 7u) >> 3;
+      ctl[L][1] = 0u;
     }
   };
 
+  // A checksum that does not match: counted, and the record's index inside its block - found by walking the
+  // block's headers again, this is rare - lowers the block's first_bad.
+  auto mismatch = [&](uint32_t blk, uint32_t start) {
+    atomicAdd(&p.counts[TCRC_CNT_MISMATCH], 1ull);
+    atomicMin(&p.counts[TCRC_CNT_FIRST_BAD], (unsigned long long)(p.block_base + blk));
+    const uint64_t base = (uint64_t)blk * kLogBlockBytes;
+    const uint64_t end = base + kLogBlockBytes < p.size ? base + kLogBlockBytes : p.size;
+    const bool last = p.tail && end == p.size;
+    uint32_t pos = 0, k = 0, hs = 0, ln = 0, code = 0;
+    while (pos + 6u < start && wal_step(p.img, base + pos, end, last, p.log_number, &hs, &ln, &code)) {
+      pos += hs + ln;
+      ++k;
+    }
+    atomicMin(&p.blocks[blk].first_bad, k);
+  };
+
   if (wave == 0) fill(0, p.first_rounds);
+  stamp(1);
   __syncthreads();
   for (int L = 0;; L ^= 1) {
-    const uint32_t nf = ctl[L][0], nbk = ctl[L][1];
-    if (nf + nbk == 0u) break;  // nothing was left to walk
-    if (wave == 0) fill(L ^ 1, (uint32_t)kWalListRounds);
+    const uint32_t nrounds = ctl[L][0];
+    if (nrounds == 0u) break;  // nothing was left to walk
+    stamp(2u + 3u * t_at);
+    if (wave == 0) fill(L ^ 1, p.list_rounds);
+    stamp(3u + 3u * t_at);
     for (;;) {
       uint32_t r = 0;
-      if (lane == 0) r = atomicAdd(&ctl[L][2], 1u);
+      if (lane == 0) r = atomicAdd(&ctl[L][1], 1u);
       r = (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
-      if (r >= nf + nbk) break;
-      const uint32_t at = r < nf ? r * 8u : (uint32_t)kWalListEntries - 8u * (r - nf + 1u);
-      const uint2 e = list[L][at + grp];
+      if (r >= nrounds) break;
+      const uint2 e = list[L][r * 8u + grp];
       const bool valid = (e.x & kWalEntryValid) != 0u;
       const bool first = (e.x & kWalEntryFirst) != 0u;
-      const uint32_t blk = e.x & 0xfffffu, q = (e.x >> 20) & 7u;
+      const uint32_t blk = e.x & 0x7ffffu, q = (e.x >> 19) & 31u, slot = e.x >> 26;
       const uint32_t start = e.y & 0x7fffu, len = e.y >> 15;
       const uint8_t* ptr = p.img + (uint64_t)blk * kLogBlockBytes + start;
       // the stored value is fetched now so its latency hides behind the row loop
@@ -732,36 +770,36 @@ __global__ __launch_bounds__(kThreads) void k_wal_fused(WalScanParams p) {
       if (valid && first && j == G - 1) __builtin_memcpy(&stored, ptr - 6, 4);
       const uint32_t core = span_remainder<G, NT>(lds, LB, lane, ptr, len, first ? 0u : 0xffffffffu, valid, false,
                                                   (const uint8_t*)p.tab_main);
-      // chunk remainders, advanced through the bytes behind them, are XORed towards the span's first chunk:
-      // the group q chunks before a span's end takes in the q groups after it
-      uint32_t v = 0;
-      if (valid && j == G - 1) v = q ? gf2_mulmod_dev(core, pow_chunk[q]) : core;
-#pragma unroll
-      for (int d = 1; d < 8; d <<= 1) {
-        const uint32_t t = __shfl_down(v, (unsigned)(G * d));
-        if (q >= (uint32_t)d) v ^= t;
-      }
-      if (valid && first && j == G - 1) {
-        const uint32_t crc = ~v;
-        const uint32_t masked = ((crc >> 15) | (crc << 17)) + kMaskDelta;
-        if (stored != masked) {
-          atomicAdd(&p.counts[TCRC_CNT_MISMATCH], 1ull);
-          atomicMin(&p.counts[TCRC_CNT_FIRST_BAD], (unsigned long long)(p.block_base + blk));
-          // rare: the record's index inside its block is found by walking the block's headers again
-          const uint64_t base = (uint64_t)blk * kLogBlockBytes;
-          const uint64_t end = base + kLogBlockBytes < p.size ? base + kLogBlockBytes : p.size;
-          const bool last = p.tail && end == p.size;
-          uint32_t pos = 0, k = 0, hs = 0, ln = 0, code = 0;
-          while (pos + 6u < start && wal_step(p.img, base + pos, end, last, p.log_number, &hs, &ln, &code)) {
-            pos += hs + ln;
-            ++k;
+      if (valid && j == G - 1) {
+        if (slot == kWalNoSlot) {
+          const uint32_t crc = ~core;
+          if (stored != ((crc >> 15) | (crc << 17)) + kMaskDelta) mismatch(blk, start);
+        } else {
+          WalSlot* sl = &slots[L][slot];
+          if (first) {
+            __hip_atomic_store(&sl->stored, stored, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&sl->blk, blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&sl->start, start, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           }
-          atomicMin(&p.blocks[blk].first_bad, k);
+          const uint32_t v = q ? gf2_mulmod_dev(core, pow_piece[q]) : core;
+          (void)__hip_atomic_fetch_xor(&sl->acc, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          // release what this piece left in the slot, acquire what the others left
+          const uint32_t before = __hip_atomic_fetch_sub(&sl->remaining, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (before == 1u) {
+            const uint32_t crc = ~__hip_atomic_load(&sl->acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint32_t want = __hip_atomic_load(&sl->stored, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (want != ((crc >> 15) | (crc << 17)) + kMaskDelta)
+              mismatch(__hip_atomic_load(&sl->blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP),
+                       __hip_atomic_load(&sl->start, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+          }
         }
       }
     }
+    stamp(4u + 3u * t_at);
+    ++t_at;
     __syncthreads();
   }
+  stamp(31);
   if (wave == 0) {
     uint32_t total = w_records;
 #pragma unroll
@@ -773,15 +811,13 @@ __global__ __launch_bounds__(kThreads) void k_wal_fused(WalScanParams p) {
         // word and count themselves off; the last one takes the sum out (leaving both words zero for the next
         // launch) and adds it to the caller's word in pinned host memory.  The additions are acknowledged
         // before the count-off is issued (see seg_arrive).
-        (void)__hip_atomic_fetch_add(p.records_dev, (unsigned long long)total, __ATOMIC_RELAXED,
-                                     __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long* w = p.launch_words;
+        (void)__hip_atomic_fetch_add(w, (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned long long before =
-            __hip_atomic_fetch_add(p.records_dev + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long before = __hip_atomic_fetch_add(w + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (before + 1ull == (unsigned long long)gridDim.x) {
-          const unsigned long long sum =
-              __hip_atomic_exchange(p.records_dev, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          (void)__hip_atomic_exchange(p.records_dev + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned long long sum = __hip_atomic_exchange(w, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          (void)__hip_atomic_exchange(w + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           *p.records_host += sum;  // launches of one stream run one after the other
         }
       }
@@ -930,13 +966,23 @@ int run_segments(tcrc_ctx* ctx, BatchParams p, const LongArgs& la, void* stream)
 int run_wal_scan(tcrc_ctx* ctx, WalScanParams p, void* stream) {
   if (!ctx) return fail(TCRC_ERR_INVALID, "null context");
   if (p.nblocks == 0) return TCRC_OK;
-  if (p.nblocks > kWalMaxBlocks) return fail(TCRC_ERR_TOO_LARGE, "log slice above 32 GiB");
-  if (!p.img || !p.blocks || !p.counts) return fail(TCRC_ERR_INVALID, "null argument");
+  if (p.nblocks > kWalMaxBlocks) return fail(TCRC_ERR_TOO_LARGE, "log slice above 16 GiB");
+  if (!p.img || !p.blocks || !p.counts || (p.records_host && !p.launch_words))
+    return fail(TCRC_ERR_INVALID, "null argument");
   const int gi = geo_index(8);
   p.tab_main = ctx->d_tab_main[gi];
   p.tab_aux = ctx->d_tab_aux[gi];
-  for (uint32_t q = 0; q < 8; ++q) p.pow_chunk[q] = tcrc::gf2_xpow(8ull * kWalChunk * q);
+  for (uint32_t q = 0; q < 16; ++q) p.pow_piece[q] = tcrc::gf2_xpow(8ull * kWalPiece * q);
   p.first_rounds = kWalFirstFillRounds;
+  // A workgroup with little to walk (a few dozen blocks) is done walking long before it is done checksumming:
+  // shorter lists then mean shorter phases and a shorter wait for what the walker found last (measured on a
+  // 256 MiB log: 82-87 us with 96 rounds, 81-83 us with 48; a 2 GB log: 359 us with 96, 375 us with 48).
+  p.list_rounds = p.nblocks / (uint32_t)ctx->cus < 64u ? kWalListRounds / 2 : kWalListRounds;
+  if (const char* e = getenv("TCRC_WAL_LIST_ROUNDS")) {  // experiments only
+    const int v = atoi(e);
+    if (v >= 8 && v <= kWalListRounds) p.list_rounds = (uint32_t)v;
+  }
+  p.trace = (unsigned long long*)ctx->wal_trace;
   // chunks of up to 64 blocks (one per walker lane), at least two chunks per workgroup
   p.chunk_shift = 6;
   while (p.chunk_shift > 0 && (p.nblocks >> p.chunk_shift) < 2u * (uint32_t)ctx->cus) --p.chunk_shift;

@@ -110,8 +110,8 @@ struct LongArgs {
 struct NoLongArgs {};
 
 // One launch of the log scan (tcrc_engine.hip: k_wal_fused) over a slice of a log image.
-constexpr uint32_t kWalChunk = 4096;        // spans longer than this are cut into chunks of this size (from their end)
-constexpr uint32_t kWalMaxBlocks = 1u << 20;  // 32 KiB blocks per launch (the entry format keeps 20 bits of block index)
+constexpr uint32_t kWalPiece = 2048;          // spans longer than this are cut into pieces of this size (from their end)
+constexpr uint32_t kWalMaxBlocks = 1u << 19;  // 32 KiB blocks per launch (the entry format keeps 19 bits of block index)
 struct WalScanParams {
   const uint8_t* img;          // first byte of the slice (a 32 KiB block boundary of the file)
   uint64_t size;               // bytes in the slice (the last block may be short)
@@ -120,13 +120,16 @@ struct WalScanParams {
   uint32_t nblocks;
   uint32_t tail;               // the slice ends where the file ends
   uint32_t chunk_shift;        // log2 of the blocks per chunk dealt to a workgroup at a time
+  uint32_t list_rounds;        // rounds the later lists are cut off at (at most what a list holds)
   uint32_t first_rounds;       // rounds the first list is cut off at (the checksums start once it is filled)
   tcrc_wal_block* blocks;      // [nblocks]
   unsigned long long* counts;  // the caller's TCRC_CNT_* block (accumulated into)
   unsigned long long* records_host;  // when not NULL: the launch's candidate records are added to this word of
-                                     // pinned host memory by the last workgroup to finish ...
-  unsigned long long* records_dev;   // ... which uses these two device words (zero before and after a launch)
-  uint32_t pow_chunk[8];       // x^(8 * kWalChunk * q) mod P
+                                     // pinned host memory by the last workgroup to finish
+  unsigned long long* launch_words;  // with records_host: two device words, zero before and after a launch
+                                     // (records so far, workgroups done)
+  uint32_t pow_piece[16];      // x^(8 * kWalPiece * q) mod P
+  unsigned long long* trace;   // development aid, normally NULL: 32 timestamps (100 MHz) per workgroup, see k_wal_fused
   const uint32_t* tab_main;
   const uint32_t* tab_aux;
 };
@@ -204,6 +207,7 @@ struct tcrc_ctx {
   // log-scan scratch (tcrc_wal.hip): one scan at a time per context
   std::mutex wal_mu;
   tcrc_scratch wal_misc, wal_list_counts, wal_list_first, wal_list_temp, wal_frags;
+  void* wal_trace = nullptr;  // development aid: device buffer of 32 x 8 bytes per CU the next scans write timestamps to
   uint64_t wal_calls = 0;  // picks the record-counter slot of a scan (guarded by wal_mu)
   unsigned long long* wal_pin = nullptr;  // 32 words of pinned host memory the scan kernels report record counts into
   // host-pointer entry points (tcrc_host.hip): their own stream and staging, one call at a time

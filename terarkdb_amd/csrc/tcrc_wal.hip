@@ -4,7 +4,7 @@
 // A log file is a sequence of 32 KiB blocks; physical records never cross a block
 // boundary (db/log_writer.cc:58-80), so every block can be parsed on its own.  The
 // scan follows db/log_reader.cc:314-406 (ReadPhysicalRecord) for a complete image
-// read without retries, in ONE kernel launch per 32 GiB: header walk (structural checks,
+// read without retries, in ONE kernel launch per 16 GiB: header walk (structural checks,
 // db/log_reader.cc:317-384) and checksums (db/log_reader.cc:388-390) run side by side in every workgroup.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
@@ -288,7 +288,7 @@ extern "C" int tcrc_dev_wal_verify_part(tcrc_ctx* ctx, const void* d_img, uint64
   // The record count goes back to the host only if it is asked for, and then without a copy command: the
   // kernels add it into one of 32 words of pinned host memory (a slot per call, so that a scan still running
   // on another stream does not disturb it) through two device words of the same slot.
-  unsigned long long *d_records = nullptr, *pin_records = nullptr;
+  unsigned long long *d_words = nullptr, *pin_records = nullptr;
   if (h_records) {
     std::lock_guard<std::mutex> lock(ctx->wal_mu);
     if (!ctx->wal_misc.p) {
@@ -298,7 +298,7 @@ extern "C" int tcrc_dev_wal_verify_part(tcrc_ctx* ctx, const void* d_img, uint64
     if (!ctx->wal_pin)
       HIP_TRY(hipHostMalloc((void**)&ctx->wal_pin, 32 * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent));
     const uint64_t slot = ctx->wal_calls++ % 32;
-    d_records = (unsigned long long*)ctx->wal_misc.p + 2 * slot;
+    d_words = (unsigned long long*)ctx->wal_misc.p + 2 * slot;
     pin_records = ctx->wal_pin + slot;
     *pin_records = 0;
   }
@@ -315,7 +315,7 @@ extern "C" int tcrc_dev_wal_verify_part(tcrc_ctx* ctx, const void* d_img, uint64
     w.blocks = d_blocks + b0;
     w.counts = (unsigned long long*)d_counts;
     w.records_host = pin_records;
-    w.records_dev = d_records;
+    w.launch_words = d_words;
     if (int rc = run_wal_scan(ctx, w, stream)) return rc;
   }
   uint64_t total_records = 0;
@@ -324,5 +324,13 @@ extern "C" int tcrc_dev_wal_verify_part(tcrc_ctx* ctx, const void* d_img, uint64
     total_records = *(volatile unsigned long long*)pin_records;
   }
   if (h_records) *h_records = total_records;
+  return TCRC_OK;
+}
+
+// Development aid (not part of the C ABI in include/): scans of this context write per-workgroup phase
+// timestamps (32 x uint64 per CU, 100 MHz ticks) into d_trace until it is set back to NULL.
+extern "C" int tcrc_debug_wal_trace(tcrc_ctx* ctx, void* d_trace) {
+  if (!ctx) return fail(TCRC_ERR_INVALID, "null context");
+  ctx->wal_trace = d_trace;
   return TCRC_OK;
 }

@@ -94,7 +94,8 @@ def test_running_totals():
     eng.counts_reset(counts)
     eng.wal_verify(G.to_dev(img), img.size, 123, blocks, counts)
     st = eng.stats()
-    assert st["batch_launches"] >= 6 and st["batch_buffers"] >= 64 + 32
+    # two stamps, the long buffer and the short host input; the log scan has a kernel of its own
+    assert st["batch_launches"] == 4 and st["batch_buffers"] >= 64 + 32
     assert (st["long_calls"], st["long_bytes"]) == (1, 200000)
     assert (st["log_images"], st["log_bytes"]) == (1, img.size)
     assert st["host_calls"] == 1 and st["host_bytes_in"] == 1000 and st["host_nanos"] > 0
