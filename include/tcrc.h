@@ -262,6 +262,25 @@ int tcrc_host_wal_list(tcrc_ctx* ctx, const void* h_img, uint64_t size, uint64_t
 int tcrc_extend(tcrc_ctx* ctx, uint32_t init, const void* h_data, size_t n, uint32_t* out);
 int tcrc_value(tcrc_ctx* ctx, const void* h_data, size_t n, uint32_t* out);
 
+/* ---- the reference's own scalar signature ------------------------------------------ */
+/* uint32_t (*)(uint32_t, const char*, size_t): the type of the pointer the reference dispatches
+ * crc32c::Extend through (`typedef uint32_t (*Function)(...)`, util/crc32c.cc:439; `ChosenExtend`,
+ * util/crc32c.cc:1225-1228), so an integration can write `ChosenExtend = tcrc_crc32c_extend;`.
+ * Returns crc32c::Extend(init, data, n), computed on the GPU of a process-wide default context that the
+ * first call creates (device from the environment variable TCRC_DEVICE, default 0); calls are serialised
+ * inside that context, short inputs take the path without copy commands.  One call is a device round trip
+ * (about 16 us), so this is for completeness of the boundary, not for per-record use.
+ *
+ * The signature leaves no room for an error, and the library holds no CPU implementation of the checksum.
+ * tcrc_set_scalar_fallback hands in the function to call instead when there is no GPU or the engine fails -
+ * the reference's own ExtendImpl<...> / crc32c_3way, i.e. what ChosenExtend pointed to before.  Without a
+ * fallback such a call prints the engine's error and aborts the process.  tcrc_scalar_fallback_calls counts
+ * the calls that went to the fallback. */
+typedef uint32_t (*tcrc_extend_fn)(uint32_t init, const char* data, size_t n);
+uint32_t tcrc_crc32c_extend(uint32_t init, const char* data, size_t n);
+void tcrc_set_scalar_fallback(tcrc_extend_fn fn);
+uint64_t tcrc_scalar_fallback_calls(void);
+
 /* ---- measurement aid ----------------------------------------------------------- */
 /* Streams nbytes from d_base with loads only (no checksum work) so a benchmark can report
  * the read rate this device actually reaches beside the CRC kernels' rate.  d_scratch

@@ -59,6 +59,7 @@ SIGNATURES = {
     "tcrc_dev_batch_verify": (_i, [_vp, _vp, _vp, _u64, _vp, _u32, _vp, _vp, _vp, _vp, _vp]),
 }
 _sz = C.c_size_t
+EXTEND_FN = C.CFUNCTYPE(_u32, _u32, _vp, _sz)  # the reference's `Function` type (util/crc32c.cc:439)
 STAMP_FN = C.CFUNCTYPE(_i, _vp, _vp, _sz, C.POINTER(Desc), _sz, C.POINTER(_u32))
 SCAN_FN = C.CFUNCTYPE(_i, _vp, _vp, _sz, _u64, C.POINTER(WalBlock))
 CHECK_FN = C.CFUNCTYPE(_i, _vp, _vp, _sz, C.POINTER(Desc), _sz, C.POINTER(_u32), C.POINTER(C.c_uint8))
@@ -81,6 +82,9 @@ SIGNATURES.update({
     "tcrc_debug_tables": (_i, [_i, _vp, _vp, _sz, C.POINTER(_sz)]),
     "tcrc_extend": (_i, [_vp, _u32, _vp, _sz, C.POINTER(_u32)]),
     "tcrc_value": (_i, [_vp, _vp, _sz, C.POINTER(_u32)]),
+    "tcrc_crc32c_extend": (_u32, [_u32, _vp, _sz]),
+    "tcrc_set_scalar_fallback": (None, [_vp]),
+    "tcrc_scalar_fallback_calls": (_u64, []),
     "tcrc_shim_memfile_new": (_vp, []),
     "tcrc_shim_memfile_free": (None, [_vp]),
     "tcrc_shim_memfile_size": (_sz, [_vp]),

@@ -4,6 +4,8 @@
 // by the host link, not by the kernels.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <atomic>
@@ -530,6 +532,52 @@ int tcrc_extend(tcrc_ctx* ctx, uint32_t init, const void* h_data, size_t n, uint
 
 int tcrc_value(tcrc_ctx* ctx, const void* h_data, size_t n, uint32_t* out) {
   return tcrc_extend(ctx, 0, h_data, n, out);
+}
+
+// ---- the reference's scalar signature (util/crc32c.cc:439,1225-1228) over a process-wide context ----
+namespace {
+std::mutex g_scalar_mu;
+tcrc_ctx* g_scalar_ctx = nullptr;
+bool g_scalar_tried = false;
+std::string g_scalar_init_error;
+std::atomic<tcrc_extend_fn> g_scalar_fallback{nullptr};
+std::atomic<uint64_t> g_scalar_fallback_calls{0};
+
+tcrc_ctx* scalar_context() {
+  std::lock_guard<std::mutex> lock(g_scalar_mu);
+  if (!g_scalar_tried) {
+    g_scalar_tried = true;
+    int device = 0;
+    if (const char* e = getenv("TCRC_DEVICE")) device = atoi(e);
+    if (tcrc_init(device, &g_scalar_ctx) != TCRC_OK) {
+      g_scalar_ctx = nullptr;
+      g_scalar_init_error = tcrc_last_error();
+    }
+  }
+  return g_scalar_ctx;
+}
+}  // namespace
+
+void tcrc_set_scalar_fallback(tcrc_extend_fn fn) { g_scalar_fallback.store(fn); }
+
+uint64_t tcrc_scalar_fallback_calls(void) { return g_scalar_fallback_calls.load(); }
+
+uint32_t tcrc_crc32c_extend(uint32_t init, const char* data, size_t n) {
+  if (n == 0) return init;  // util/crc32c.cc:356-398 over no bytes
+  std::string why;
+  if (tcrc_ctx* ctx = scalar_context()) {
+    uint32_t out = 0;
+    if (tcrc_extend(ctx, init, data, n, &out) == TCRC_OK) return out;
+    why = tcrc_last_error();
+  } else {
+    why = g_scalar_init_error;
+  }
+  if (tcrc_extend_fn fb = g_scalar_fallback.load()) {
+    g_scalar_fallback_calls.fetch_add(1, std::memory_order_relaxed);
+    return fb(init, data, n);
+  }
+  fprintf(stderr, "tcrc_crc32c_extend: %s, and no fallback was set with tcrc_set_scalar_fallback\n", why.c_str());
+  abort();
 }
 
 }  // extern "C"
