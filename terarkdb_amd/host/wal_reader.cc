@@ -10,18 +10,58 @@
 namespace terarkdb_amd {
 namespace log {
 
+Reader::BlockWindow::BlockWindow(SequentialFile* f)
+    : file(f), store(new char[kBlockSize]), present(0), end_offset(0), ended(false), failed(false) {}
+
+Reader::BlockWindow::~BlockWindow() { delete[] store; }
+
+Reader::BlockWindow::Result Reader::BlockWindow::NextBlock(Status* why) {
+  if (ended || failed) return kNothing;
+  Slice got;
+  *why = file->Read(kBlockSize, &got, store);
+  if (got.size() && got.data() != store) memmove(store, got.data(), got.size());
+  present = got.size();
+  end_offset += present;
+  if (!why->ok()) {
+    unread.clear();
+    failed = true;
+    return kFailed;
+  }
+  unread = Slice(store, present);
+  ended = !block_complete();
+  return kMore;
+}
+
+Reader::BlockWindow::Result Reader::BlockWindow::Grow(size_t* added, Status* why) {
+  *added = 0;
+  if (failed) return kNothing;
+  ended = false;
+  if (block_complete()) return kNothing;  // nothing of this block is missing: the next read starts a new one
+  const size_t missing = kBlockSize - present;
+  const size_t unread_at = present - unread.size();
+  if (unread.size() && unread.data() != store + unread_at) memmove(store + unread_at, unread.data(), unread.size());
+  Slice got;
+  *why = file->Read(missing, &got, store + present);
+  *added = got.size();
+  end_offset += *added;
+  if (!why->ok()) {
+    failed = true;
+    return kFailed;
+  }
+  if (*added && got.data() != store + present) memmove(store + present, got.data(), *added);
+  present += *added;
+  unread = Slice(store + unread_at, present - unread_at);
+  ended = !block_complete();
+  return kMore;
+}
+
 Reader::Reader(std::unique_ptr<SequentialFile>&& file, Reporter* reporter, bool checksum, uint64_t log_num,
                bool retry_after_eof, RecordVerifier* verifier)
     : file_(std::move(file)),
       reporter_(reporter),
       checksum_(checksum),
-      backing_store_(new char[kBlockSize]),
-      buffer_(),
-      eof_(false),
-      read_error_(false),
-      eof_offset_(0),
+      win_(file_.get()),
       last_record_offset_(0),
-      end_of_buffer_offset_(0),
       log_number_(log_num),
       recycled_(false),
       retry_after_eof_(retry_after_eof),
@@ -31,13 +71,13 @@ Reader::Reader(std::unique_ptr<SequentialFile>&& file, Reporter* reporter, bool 
       next_index_(0),
       verifier_calls_(0) {}
 
-Reader::~Reader() { delete[] backing_store_; }
+Reader::~Reader() {}
 
 void Reader::Drop(size_t bytes, const Status& why) {
   if (reporter_ != nullptr) reporter_->Corruption(bytes, why);
 }
 
-// buffer_ now holds different bytes: whatever was known about its checksums is void.
+// the window now holds different unread bytes: whatever was known about its checksums is void.
 // Record indices count from the start of the 32 KiB block.
 void Reader::BufferChanged(bool new_block) {
   verdict_known_ = false;
@@ -45,15 +85,15 @@ void Reader::BufferChanged(bool new_block) {
   if (new_block) next_index_ = 0;
 }
 
-// Is the checksum of the record at the front of buffer_ good?  (The comparison the
+// Is the checksum of the first unread record good?  (The comparison the
 // reference makes at db/log_reader.cc:388-390, answered by the engine.)
 bool Reader::ChecksumGood() {
   if (!verdict_known_) {
-    // buffer_ never spans two blocks, so its last byte names the block
-    const uint64_t block = (end_of_buffer_offset_ - 1) / kBlockSize;
+    // the window never spans two blocks, so its last byte names the block
+    const uint64_t block = (win_.end_offset - 1) / kBlockSize;
     bool from_image = false;
-    if (image_ && end_of_buffer_offset_ <= image_->size && block < image_->blocks.size()) {
-      // every byte of buffer_ was in the verified image, whose walk of this block met the
+    if (image_ && win_.end_offset <= image_->size && block < image_->blocks.size()) {
+      // every unread byte was in the verified image, whose walk of this block met the
       // same records in the same order
       first_bad_ = image_->blocks[block].first_bad;
       from_image = true;
@@ -62,7 +102,7 @@ bool Reader::ChecksumGood() {
       tcrc_wal_block one;
       memset(&one, 0, sizeof(one));
       one.first_bad = 0xffffffffu;
-      Status s = verifier_ ? verifier_->ScanBlocks(buffer_.data(), buffer_.size(), log_number_, &one)
+      Status s = verifier_ ? verifier_->ScanBlocks(win_.unread.data(), win_.unread.size(), log_number_, &one)
                            : Status::NotSupported("log reader has no checksum verifier");
       ++verifier_calls_;
       if (!s.ok()) {
@@ -70,7 +110,7 @@ bool Reader::ChecksumGood() {
         Drop(0, s);
         first_bad_ = next_index_;
       } else {
-        // the scan counted from the front of buffer_
+        // the scan counted from the first unread record
         first_bad_ = one.first_bad == 0xffffffffu ? one.first_bad : next_index_ + one.first_bad;
       }
     }
@@ -79,125 +119,102 @@ bool Reader::ChecksumGood() {
   return next_index_ != first_bad_;
 }
 
-// Brings more bytes into buffer_ (db/log_reader.cc:276-312).
+// Brings more bytes into the window when the unread part is too short for what is being parsed; the
+// behaviour is that of db/log_reader.cc:276-312.  false: *error is what the caller returns.
 bool Reader::Refill(size_t* drop_size, int* error) {
-  if (!eof_ && !read_error_) {
-    buffer_.clear();
-    Status status = file_->Read(kBlockSize, &buffer_, backing_store_);
-    end_of_buffer_offset_ += buffer_.size();
-    BufferChanged(true);
-    if (!status.ok()) {
-      buffer_.clear();
-      Drop(kBlockSize, status);
-      read_error_ = true;
+  Status why;
+  switch (win_.NextBlock(&why)) {
+    case BlockWindow::kMore:
+      BufferChanged(true);
+      return true;
+    case BlockWindow::kFailed:
+      BufferChanged(true);
+      Drop(kBlockSize, why);
       *error = kEof;
       return false;
-    }
-    if (buffer_.size() < static_cast<size_t>(kBlockSize)) {
-      eof_ = true;
-      eof_offset_ = buffer_.size();
-    }
-    return true;
+    case BlockWindow::kNothing:
+      break;
   }
-  if (retry_after_eof_ && !read_error_) {
+  // The file has ended (or failed) earlier.  A tailing reader looks whether it has grown since.
+  if (retry_after_eof_ && !win_.failed) {
     UnmarkEOF();
-    return !read_error_;
+    return !win_.failed;
   }
-  // A non-empty rest here is a header cut short at the end of the file: the writer may
-  // have died while writing it.  Reported only when the caller asks for it.
-  if (buffer_.size()) {
-    *drop_size = buffer_.size();
-    buffer_.clear();
-    *error = kBadHeader;
-    return false;
-  }
-  buffer_.clear();
-  *error = kEof;
+  // What is left unread is a header cut short by the end of the file - the writer may have died while
+  // writing it.  It is dropped; whether that is worth a report is the caller's decision.
+  *drop_size = win_.unread.size();
+  win_.unread.clear();
+  *error = *drop_size ? kBadHeader : kEof;
   return false;
 }
 
-// After an end of file in the middle of a block: read the rest of that block
-// (db/log_reader.cc:202-264).
+// The file may have grown behind an end of file met earlier: takes in what has arrived of the block that
+// was cut short (db/log_reader.cc:202-264).
 void Reader::UnmarkEOF() {
-  if (read_error_) return;
-  eof_ = false;
-  if (!retry_after_eof_ && eof_offset_ == 0) return;
-
-  const size_t consumed = eof_offset_ - buffer_.size();
-  const size_t want = kBlockSize - eof_offset_;
-  if (buffer_.data() != backing_store_ + consumed) {
-    memmove(backing_store_ + consumed, buffer_.data(), buffer_.size());
-  }
-  Slice got;
-  Status status = file_->Read(want, &got, backing_store_ + eof_offset_);
-  const size_t added = got.size();
-  end_of_buffer_offset_ += added;
-  if (!status.ok()) {
-    if (added > 0) Drop(added, status);
-    read_error_ = true;
+  if (win_.failed) return;
+  // Without retries there is nothing to complete unless the file ended inside a block.
+  if (!retry_after_eof_ && (win_.present == 0 || win_.block_complete())) {
+    win_.ended = false;
     return;
   }
-  if (got.data() != backing_store_ + eof_offset_) memmove(backing_store_ + eof_offset_, got.data(), added);
-  buffer_ = Slice(backing_store_ + consumed, eof_offset_ + added - consumed);
-  if (added > 0) {
-    // the records still in front keep their places, but new ones may have arrived: ask again
-    BufferChanged(false);
+  size_t added = 0;
+  Status why;
+  const BlockWindow::Result r = win_.Grow(&added, &why);
+  if (r == BlockWindow::kFailed) {
+    if (added > 0) Drop(added, why);
+    return;
   }
-  if (added < want) {
-    eof_ = true;
-    eof_offset_ += added;
-  } else {
-    eof_offset_ = 0;
-  }
+  // the records still unread keep their places in the block, but new ones may have arrived behind them
+  if (r == BlockWindow::kMore && added > 0) BufferChanged(false);
 }
 
 // One physical record (db/log_reader.cc:314-406).
 unsigned int Reader::NextPhysical(Slice* payload, size_t* drop_size) {
   for (;;) {
-    if (buffer_.size() < static_cast<size_t>(kHeaderSize)) {
+    if (win_.unread.size() < static_cast<size_t>(kHeaderSize)) {
       int why = kEof;
       if (!Refill(drop_size, &why)) return why;
       continue;
     }
-    const char* header = buffer_.data();
+    const char* header = win_.unread.data();
     const uint32_t length = (static_cast<uint32_t>(header[4]) & 0xff) | ((static_cast<uint32_t>(header[5]) & 0xff) << 8);
     const unsigned int type = header[6];  // through char, as the reference does
     size_t header_size = kHeaderSize;
     if (type >= kRecyclableFullType && type <= kRecyclableLastType) {
-      if (end_of_buffer_offset_ - buffer_.size() == 0) recycled_ = true;
+      if (win_.unread_offset() == 0) recycled_ = true;
       header_size = kRecyclableHeaderSize;
-      if (buffer_.size() < header_size) {
+      if (win_.unread.size() < header_size) {
         int why = kEof;
         if (!Refill(drop_size, &why)) return why;
         continue;
       }
       if (static_cast<uint64_t>(DecodeFixed32(header + 7)) != log_number_) return kOldRecord;
     }
-    if (header_size + length > buffer_.size()) {
+    if (header_size + length > win_.unread.size()) {
       if (retry_after_eof_) {
         int why = kEof;
         if (!Refill(drop_size, &why)) return why;
         continue;
       }
-      *drop_size = buffer_.size();
-      buffer_.clear();
-      if (!eof_) return kBadRecordLen;
+      *drop_size = win_.unread.size();
+      win_.unread.clear();
+      if (!win_.ended) return kBadRecordLen;
       // the file ends before the payload does: the writer presumably died mid-record
       return *drop_size ? kBadHeader : kEof;
     }
     if (type == kZeroType && length == 0) {
       // preallocated file space; skipped without a report
-      buffer_.clear();
+      win_.unread.clear();
       return kBadRecord;
     }
     if (checksum_ && !ChecksumGood()) {
       // "length" itself may be what is corrupt, so nothing after this record in the block is trusted
-      *drop_size = buffer_.size();
-      buffer_.clear();
+      *drop_size = win_.unread.size();
+      win_.unread.clear();
       return kBadRecordChecksum;
     }
     ++next_index_;
-    buffer_.remove_prefix(header_size + length);
+    win_.unread.remove_prefix(header_size + length);
     *payload = Slice(header + header_size, length);
     return type;
   }
@@ -229,7 +246,7 @@ bool Reader::ReadRecord(Slice* record, std::string* scratch, WALRecoveryMode mod
 
   Slice fragment;
   for (;;) {
-    const uint64_t physical_offset = end_of_buffer_offset_ - buffer_.size();
+    const uint64_t physical_offset = win_.unread_offset();
     size_t drop_size = 0;
     const unsigned int what = NextPhysical(&fragment, &drop_size);
 

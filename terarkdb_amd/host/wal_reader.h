@@ -39,7 +39,7 @@ class Reader {
   bool ReadRecord(Slice* record, std::string* scratch,
                   WALRecoveryMode wal_recovery_mode = WALRecoveryMode::kTolerateCorruptedTailRecords);
   uint64_t LastRecordOffset() const { return last_record_offset_; }
-  bool IsEOF() const { return eof_; }
+  bool IsEOF() const { return win_.ended; }
   void UnmarkEOF();
   SequentialFile* file() { return file_.get(); }
   // How many times the verifier had to be asked (0 when an attached image covered the file).
@@ -64,26 +64,45 @@ class Reader {
   void Drop(size_t bytes, const Status& why);
   void DropCorrupt(size_t bytes, const char* why) { Drop(bytes, Status::Corruption(why)); }
 
+  // The 32 KiB block of the file the reader is looking at: how much of it is in memory, which part of that is
+  // still unread, and whether the file ended inside it (db/log_reader.cc keeps the same facts in
+  // backing_store_, buffer_, eof_, eof_offset_ and end_of_buffer_offset_).
+  struct BlockWindow {
+    enum Result { kMore, kNothing, kFailed };
+    explicit BlockWindow(SequentialFile* f);
+    ~BlockWindow();
+    // Forgets the current block and reads the next one.  kFailed: *why says what the file reported.
+    Result NextBlock(Status* why);
+    // The file had ended inside (or exactly in front of) the current block: reads what has been appended
+    // since, up to the end of the block, behind the bytes already there.  *added = bytes that came.
+    Result Grow(size_t* added, Status* why);
+    bool block_complete() const { return present == static_cast<size_t>(kBlockSize); }
+    uint64_t unread_offset() const { return end_offset - unread.size(); }  // file offset of unread's first byte
+
+    SequentialFile* const file;
+    char* const store;    // kBlockSize bytes
+    size_t present;       // bytes of the current block in store
+    Slice unread;         // the tail of those bytes not consumed yet
+    uint64_t end_offset;  // file offset just past the bytes in store
+    bool ended;           // the last read came back short: the file ended there (for now)
+    bool failed;          // a read failed: nothing more will be read
+  };
+
   const std::unique_ptr<SequentialFile> file_;
   Reporter* const reporter_;
   const bool checksum_;
-  char* const backing_store_;
-  Slice buffer_;  // unread part of the current block
-  bool eof_;         // the last read came back short
-  bool read_error_;
-  size_t eof_offset_;  // bytes of the current block present when EOF was hit
+  BlockWindow win_;
   uint64_t last_record_offset_;
-  uint64_t end_of_buffer_offset_;  // file offset just past buffer_
   const uint64_t log_number_;
   bool recycled_;
   const bool retry_after_eof_;
 
-  // verdict state for the records of buffer_
+  // verdict state for the unread records of the window
   RecordVerifier* const verifier_;
   std::shared_ptr<const VerifiedLogImage> image_;
-  bool verdict_known_;      // first_bad_ is valid for the records now in buffer_
+  bool verdict_known_;      // first_bad_ is valid for the records now unread in the window
   uint32_t first_bad_;      // index within the 32 KiB block of the first record failing its CRC
-  uint32_t next_index_;     // index within the 32 KiB block of the record at the front of buffer_
+  uint32_t next_index_;     // index within the 32 KiB block of the first unread record
   uint64_t verifier_calls_;
 
   Reader(const Reader&) = delete;

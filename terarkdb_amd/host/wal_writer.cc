@@ -28,24 +28,24 @@ Writer::~Writer() {
   if (stage_) stamper_->FreeStaging(stage_);
 }
 
-void Writer::Reserve(size_t more) {
-  if (stage_size_ + more <= stage_cap_) return;
+bool Writer::Reserve(size_t more) {
+  if (stage_size_ + more <= stage_cap_) return true;
   // pinned allocations are slow: start at 1 MiB and grow fourfold
   size_t cap = stage_cap_ ? stage_cap_ : (size_t)1 << 20;
   while (cap < stage_size_ + more) cap *= 4;
   char* fresh = stamper_->AllocStaging(cap);
-  if (!fresh) abort();  // out of memory: like the reference's buffers, nothing sensible to continue with
+  if (!fresh) return false;  // what is staged stays as it is
   if (stage_size_) memcpy(fresh, stage_, stage_size_);
   if (stage_) stamper_->FreeStaging(stage_);
   stage_ = fresh;
   stage_cap_ = cap;
+  return true;
 }
 
 // One physical record: header with a blank checksum, then the payload
 // (layout: db/log_writer.cc:104-142; the CRC covers type, log number and payload, not the length).
 void Writer::Frame(RecordType t, const char* payload, size_t n) {
   const size_t header_size = t >= kRecyclableFullType ? kRecyclableHeaderSize : kHeaderSize;
-  Reserve(header_size + n);
   char* h = stage_ + stage_size_;
   memset(h, 0, 4);
   h[4] = static_cast<char>(n & 0xff);
@@ -70,13 +70,18 @@ Status Writer::AddRecord(const Slice& slice) {
   size_t left = slice.size();
   const size_t header_size = recycle_log_files_ ? kRecyclableHeaderSize : kHeaderSize;
   const int base = recycle_log_files_ ? kRecyclableFullType - kFullType : 0;
+  // Room for the whole logical record is taken first - its bytes, a header per fragment and one block tail -
+  // so that a failed allocation leaves nothing of it staged and comes back as a status, like a failed Append
+  // does in the reference (db/log_writer.cc:140-148).
+  const size_t fragments = left / (kBlockSize - header_size) + 2;
+  if (!Reserve(left + fragments * header_size + header_size))
+    return Status::IOError("cannot allocate staging memory for log records");
   bool first_fragment = true;
   for (;;) {
     const size_t room = kBlockSize - block_offset_;
     if (room < header_size) {
       // too small for a header: zero-fill the tail of the block and move on
       if (room > 0) {
-        Reserve(room);
         memset(stage_ + stage_size_, 0, room);
         stage_size_ += room;
       }

@@ -35,7 +35,7 @@ class Writer {
 
  private:
   void Frame(RecordType t, const char* payload, size_t n);
-  void Reserve(size_t more);
+  bool Reserve(size_t more);
   Status Submit();
 
   std::unique_ptr<WritableFile> dest_;
