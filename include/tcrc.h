@@ -49,7 +49,8 @@ typedef struct tcrc_desc {
 
 /* flags */
 #define TCRC_F_MASK 0x1u          /* outputs are Mask(crc) instead of crc */
-#define TCRC_F_EXPECT_AFTER 0x2u  /* verify: stored value is the LE32 right after the buffer (SST trailer) */
+#define TCRC_F_EXPECT_AFTER 0x2u  /* verify: stored value is the LE32 right after the buffer (SST trailer), or right
+                                     after the suffix byte when one is given - where TCRC_F_STORE_AFTER puts it */
 #define TCRC_F_EXPECT_BEFORE 0x4u /* verify: stored value is the LE32 six bytes before the buffer (WAL header) */
 #define TCRC_F_STORE_AFTER 0x8u   /* stamp: also write the block trailer into the image, right after the buffer: the
                                      suffix byte (if one is given) and then the result as LE32 - the 5-byte

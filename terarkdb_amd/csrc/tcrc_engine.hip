@@ -484,7 +484,10 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p, typename 
       if (p.expected) {
         stored = p.expected[buf];
       } else {
-        const uint8_t* e = (p.flags & TCRC_F_EXPECT_AFTER) ? p.base + off + len : p.base + off - 6;
+        // behind the buffer - and behind its suffix byte when there is one, where a stamp with
+        // TCRC_F_STORE_AFTER put it - or in front of it
+        const uint32_t sfx_bytes = (p.uniform_suffix >= 0 || p.suffix) ? 1u : 0u;
+        const uint8_t* e = (p.flags & TCRC_F_EXPECT_AFTER) ? p.base + off + len + sfx_bytes : p.base + off - 6;
         __builtin_memcpy(&stored, e, 4);  // one unaligned dword load
       }
     }

@@ -84,6 +84,13 @@ int staged_upload(tcrc_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
           failed.store(1);
           return;
         }
+      } else if (ctx->stage_recorded[i]) {
+        // the slot may still be the source of a copy that an EARLIER upload queued (a host call uploads its
+        // image and then its descriptors: the first upload returns with its last copies still in flight)
+        if (hipEventSynchronize(ctx->stage_done[i]) != hipSuccess) {
+          failed.store(1);
+          return;
+        }
       }
       const size_t off = i * S, len = bytes - off < S ? bytes - off : S;
       memcpy(ctx->stage_ring + (i % K) * S, (const char*)h_src + off, len);
@@ -101,6 +108,7 @@ int staged_upload(tcrc_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
     const size_t off = i * S, len = bytes - off < S ? bytes - off : S;
     err = hipMemcpyAsync((char*)d_dst + off, ctx->stage_ring + (i % K) * S, len, hipMemcpyHostToDevice, ctx->host_stream);
     if (err == hipSuccess) err = hipEventRecord(ctx->stage_done[i % K], ctx->host_stream);
+    if (err == hipSuccess) ctx->stage_recorded[i % K] = true;  // read by later uploads only
     issued[i].store(1, std::memory_order_release);
   }
   if (err != hipSuccess) failed.store(1);
@@ -240,9 +248,11 @@ int tcrc_host_batch_stamp(tcrc_ctx* ctx, const void* h_base, uint64_t base_bytes
   std::lock_guard<std::mutex> lock(ctx->host_mu);
   TCRC_DEVICE_SCOPE(ctx);
   if (int rc = host_begin(ctx)) return rc;
+  StreamGuard guard(ctx->host_stream);  // an error return must not leave copies from the caller's memory in flight
   if (wants_long_route(h_desc, n, h_suffix)) {
     if (int rc = check_flags_host(flags, TCRC_F_MASK)) return rc;
     if (int rc = long_route(ctx, h_base, base_bytes, h_desc, n, h_out)) return rc;
+    guard.dismiss();  // long_route returns with the stream drained
     if (flags & TCRC_F_MASK)
       for (uint64_t i = 0; i < n; ++i) h_out[i] = tcrc_mask(h_out[i]);
     return TCRC_OK;
@@ -262,6 +272,7 @@ int tcrc_host_batch_stamp(tcrc_ctx* ctx, const void* h_base, uint64_t base_bytes
                                       h_suffix ? (const uint8_t*)(ctx->zc + kZcSuffixOff) : nullptr, flags,
                                       (uint32_t*)(ctx->zc + kZcOutOff), ctx->host_stream))
       return rc;
+    guard.dismiss();
     HIP_TRY(hipStreamSynchronize(ctx->host_stream));
     memcpy(h_out, ctx->zc + kZcOutOff, n * 4);
     return TCRC_OK;
@@ -276,6 +287,7 @@ int tcrc_host_batch_stamp(tcrc_ctx* ctx, const void* h_base, uint64_t base_bytes
                                     (uint32_t*)ctx->host_out.p, ctx->host_stream))
     return rc;
   HIP_TRY(hipMemcpyAsync(h_out, ctx->host_out.p, n * 4, hipMemcpyDeviceToHost, ctx->host_stream));
+  guard.dismiss();
   HIP_TRY(hipStreamSynchronize(ctx->host_stream));
   return TCRC_OK;
 }
@@ -286,10 +298,16 @@ int tcrc_host_blocks_stamp(tcrc_ctx* ctx, const void* h_base, uint64_t n_blocks,
   if (n_blocks == 0) return TCRC_OK;
   if (!h_base || !h_out) return fail(TCRC_ERR_INVALID, "null argument");
   if (flags & TCRC_F_STORE_AFTER) return fail(TCRC_ERR_INVALID, "host entry points return the values: nothing to store into");
+  // the geometry is checked before anything is read from the caller's memory
+  if (block_len > (1u << 30)) return fail(TCRC_ERR_TOO_LARGE, "block_len above 1 GiB: use the long-buffer entry point");
+  if (n_blocks > 1 && stride < block_len) return fail(TCRC_ERR_INVALID, "stride smaller than block_len");
+  if (n_blocks > 1 && (n_blocks - 1) > (~0ull - block_len) / stride)
+    return fail(TCRC_ERR_INVALID, "n_blocks * stride overflows");
   HostCallTimer timer(ctx);
   std::lock_guard<std::mutex> lock(ctx->host_mu);
   TCRC_DEVICE_SCOPE(ctx);
   if (int rc = host_begin(ctx)) return rc;
+  StreamGuard guard(ctx->host_stream);  // an error return must not leave copies from the caller's memory in flight
   const uint64_t bytes = (n_blocks - 1) * stride + block_len;
   if (int rc = upload(ctx, &ctx->host_data, h_base, bytes)) return rc;
   if (int rc = scratch_reserve(ctx, &ctx->host_out, n_blocks * 4)) return rc;
@@ -297,6 +315,7 @@ int tcrc_host_blocks_stamp(tcrc_ctx* ctx, const void* h_base, uint64_t n_blocks,
                                      flags, (uint32_t*)ctx->host_out.p, ctx->host_stream))
     return rc;
   HIP_TRY(hipMemcpyAsync(h_out, ctx->host_out.p, n_blocks * 4, hipMemcpyDeviceToHost, ctx->host_stream));
+  guard.dismiss();
   HIP_TRY(hipStreamSynchronize(ctx->host_stream));
   return TCRC_OK;
 }
@@ -311,19 +330,21 @@ int tcrc_host_batch_verify(tcrc_ctx* ctx, const void* h_base, uint64_t base_byte
   h_counts[TCRC_CNT_CHECKED] = 0;
   if (n == 0) return TCRC_OK;
   if (!h_base || !h_desc) return fail(TCRC_ERR_INVALID, "null argument");
-  if (int rc = check_descs(h_desc, n, base_bytes, (flags & TCRC_F_EXPECT_AFTER) ? 4 : 0,
+  if (int rc = check_descs(h_desc, n, base_bytes, (flags & TCRC_F_EXPECT_AFTER) ? (h_suffix ? 5 : 4) : 0,
                            (flags & TCRC_F_EXPECT_BEFORE) != 0))
     return rc;
   HostCallTimer timer(ctx);
   std::lock_guard<std::mutex> lock(ctx->host_mu);
   TCRC_DEVICE_SCOPE(ctx);
   if (int rc = host_begin(ctx)) return rc;
+  StreamGuard guard(ctx->host_stream);  // an error return must not leave copies from the caller's memory in flight
   if (wants_long_route(h_desc, n, h_suffix)) {
     if (int rc = check_flags_host(flags, TCRC_F_MASK | TCRC_F_EXPECT_AFTER | TCRC_F_EXPECT_BEFORE)) return rc;
     if (!h_expected && !(flags & (TCRC_F_EXPECT_AFTER | TCRC_F_EXPECT_BEFORE)))
       return fail(TCRC_ERR_INVALID, "verify needs h_expected or an in-image expectation flag");
     std::vector<uint32_t> crc(n);
     if (int rc = long_route(ctx, h_base, base_bytes, h_desc, n, crc.data())) return rc;
+    guard.dismiss();  // long_route returns with the stream drained
     for (uint64_t i = 0; i < n; ++i) {
       const uint32_t masked = tcrc_mask(crc[i]);
       uint32_t stored;
@@ -364,6 +385,7 @@ int tcrc_host_batch_verify(tcrc_ctx* ctx, const void* h_base, uint64_t base_byte
                                        (uint32_t*)(ctx->zc + kZcOutOff), (uint8_t*)(ctx->zc + kZcOkOff),
                                        (uint64_t*)ctx->host_aux.p, ctx->host_stream))
       return rc;
+    guard.dismiss();
     HIP_TRY(hipStreamSynchronize(ctx->host_stream));
     if (h_out) memcpy(h_out, ctx->zc + kZcOutOff, n * 4);
     if (h_ok) memcpy(h_ok, ok, n);
@@ -393,6 +415,7 @@ int tcrc_host_batch_verify(tcrc_ctx* ctx, const void* h_base, uint64_t base_byte
   if (h_out) HIP_TRY(hipMemcpyAsync(h_out, ctx->host_out.p, n * 4, hipMemcpyDeviceToHost, ctx->host_stream));
   if (h_ok) HIP_TRY(hipMemcpyAsync(h_ok, aux + off_ok, n, hipMemcpyDeviceToHost, ctx->host_stream));
   HIP_TRY(hipMemcpyAsync(h_counts, aux, 24, hipMemcpyDeviceToHost, ctx->host_stream));
+  guard.dismiss();
   HIP_TRY(hipStreamSynchronize(ctx->host_stream));
   return TCRC_OK;
 }
@@ -420,6 +443,7 @@ int tcrc_host_wal_verify_part(tcrc_ctx* ctx, const void* h_part, uint64_t size, 
   std::lock_guard<std::mutex> lock(ctx->host_mu);
   TCRC_DEVICE_SCOPE(ctx);
   if (int rc = host_begin(ctx)) return rc;
+  StreamGuard guard(ctx->host_stream);  // an error return must not leave copies from the caller's memory in flight
   const uint64_t nblocks = (size + 32767) / 32768;
   if (int rc = upload(ctx, &ctx->host_data, h_part, size)) return rc;
   if (int rc = scratch_reserve(ctx, &ctx->host_blocks, nblocks * sizeof(tcrc_wal_block))) return rc;
@@ -433,6 +457,7 @@ int tcrc_host_wal_verify_part(tcrc_ctx* ctx, const void* h_part, uint64_t size, 
                          ctx->host_stream));
   uint64_t part_counts[TCRC_CNT_WORDS] = {0, ~0ull, 0};
   if (h_counts) HIP_TRY(hipMemcpyAsync(part_counts, ctx->host_aux.p, 24, hipMemcpyDeviceToHost, ctx->host_stream));
+  guard.dismiss();
   HIP_TRY(hipStreamSynchronize(ctx->host_stream));
   if (h_counts) {
     h_counts[TCRC_CNT_MISMATCH] += part_counts[TCRC_CNT_MISMATCH];
@@ -453,6 +478,7 @@ int tcrc_host_wal_list(tcrc_ctx* ctx, const void* h_img, uint64_t size, uint64_t
   std::lock_guard<std::mutex> lock(ctx->host_mu);
   TCRC_DEVICE_SCOPE(ctx);
   if (int rc = host_begin(ctx)) return rc;
+  StreamGuard guard(ctx->host_stream);  // an error return must not leave copies from the caller's memory in flight
   const uint64_t nblocks = (size + 32767) / 32768;
   if (int rc = upload(ctx, &ctx->host_data, h_img, size)) return rc;
   if (int rc = scratch_reserve(ctx, &ctx->host_blocks, nblocks * sizeof(tcrc_wal_block))) return rc;
@@ -473,6 +499,7 @@ int tcrc_host_wal_list(tcrc_ctx* ctx, const void* h_img, uint64_t size, uint64_t
   if (n_out)
     HIP_TRY(hipMemcpyAsync(h_records, ctx->host_records.p, n_out * sizeof(tcrc_wal_record), hipMemcpyDeviceToHost,
                            ctx->host_stream));
+  guard.dismiss();
   HIP_TRY(hipStreamSynchronize(ctx->host_stream));
   if (h_count) *h_count = total;
   return TCRC_OK;
@@ -488,6 +515,7 @@ int tcrc_extend(tcrc_ctx* ctx, uint32_t init, const void* h_data, size_t n, uint
   std::lock_guard<std::mutex> lock(ctx->host_mu);
   TCRC_DEVICE_SCOPE(ctx);
   if (int rc = host_begin(ctx)) return rc;
+  StreamGuard guard(ctx->host_stream);  // an error return must not leave copies from the caller's memory in flight
   // Pieces of up to 256 MiB, chained through init like the callers that feed a file through
   // Extend buffer by buffer (utilities/backupable/backupable_db.cc:1434-1449).
   const size_t piece = (size_t)256 << 20;
@@ -505,6 +533,7 @@ int tcrc_extend(tcrc_ctx* ctx, uint32_t init, const void* h_data, size_t n, uint
     if (int rc = tcrc_dev_blocks_stamp(ctx, base, 1, (uint32_t)n, n, init, -1, nullptr, 0,
                                        (uint32_t*)(ctx->zc + kZcOutOff), ctx->host_stream))
       return rc;
+    guard.dismiss();
     HIP_TRY(hipStreamSynchronize(ctx->host_stream));
     memcpy(&crc, ctx->zc + kZcOutOff, 4);
     *out = crc;
@@ -526,6 +555,7 @@ int tcrc_extend(tcrc_ctx* ctx, uint32_t init, const void* h_data, size_t n, uint
     memcpy(&crc, ctx->zc + kZcOutOff, 4);
     done += len;
   }
+  guard.dismiss();  // every piece's call returned with the stream drained
   *out = crc;
   return TCRC_OK;
 }

@@ -181,6 +181,19 @@ struct DeviceScope {
   if (device_scope_.err != hipSuccess)                                                                 \
   return tcrc_internal::fail(TCRC_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(device_scope_.err))
 
+// Synchronises the stream when the scope is left without dismiss(): copies issued from host memory that is
+// about to be freed or reused (a caller's buffer, a local vector, the staging ring) must not stay in flight
+// behind an error return.
+struct StreamGuard {
+  hipStream_t s;
+  bool armed = true;
+  explicit StreamGuard(hipStream_t st) : s(st) {}
+  void dismiss() { armed = false; }
+  ~StreamGuard() {
+    if (armed) (void)hipStreamSynchronize(s);
+  }
+};
+
 #define HIP_TRY(expr)                                                                                  \
   do {                                                                                                 \
     hipError_t e_ = (expr);                                                                            \
@@ -231,6 +244,7 @@ struct tcrc_ctx {
   static constexpr size_t kStageSlotBytes = (size_t)4 << 20;
   char* stage_ring = nullptr;  // kStageSlots * kStageSlotBytes of pinned memory
   hipEvent_t stage_done[kStageSlots] = {};
+  bool stage_recorded[kStageSlots] = {};  // stage_done[i] has been recorded at least once
   // running totals (tcrc_get_stats)
   std::atomic<uint64_t> st_batch_launches{0}, st_batch_buffers{0}, st_host_calls{0}, st_host_bytes_in{0},
       st_host_nanos{0}, st_log_images{0}, st_log_bytes{0}, st_long_calls{0}, st_long_bytes{0};

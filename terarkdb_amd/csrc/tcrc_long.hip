@@ -83,17 +83,6 @@ inline uint32_t segments_of(uint32_t len, uint32_t shift) {
   return len == 0 ? 1u : (uint32_t)(((uint64_t)len + (1ull << shift) - 1) >> shift);
 }
 
-// Synchronises the stream when the scope is left on an error path: copies issued from host memory that is
-// about to be freed or reused must not stay in flight.
-struct SyncOnError {
-  hipStream_t s;
-  bool armed = false;
-  explicit SyncOnError(hipStream_t st) : s(st) {}
-  ~SyncOnError() {
-    if (armed) (void)hipStreamSynchronize(s);
-  }
-};
-
 }  // namespace
 
 namespace tcrc_internal {
@@ -227,9 +216,8 @@ extern "C" int tcrc_dev_extend_long(tcrc_ctx* ctx, const void* d_base, const tcr
     if (int rc = scratch_reserve(ctx, &ctx->long_acc, (size_t)kLongLdsBuffers * 128)) return rc;
     HIP_TRY(hipMemsetAsync(ctx->long_acc.p, 0, ctx->long_acc.bytes, s));
   }
-  SyncOnError guard(s);
+  StreamGuard guard(s);  // the staging must not be left with a copy in flight
   HIP_TRY(hipMemcpyAsync(ctx->long_in.p, stage, in_bytes, hipMemcpyHostToDevice, s));
-  guard.armed = true;
   const tcrc_desc* d_bufs = (const tcrc_desc*)ctx->long_in.p;
   const uint32_t* d_first = (const uint32_t*)((const uint8_t*)ctx->long_in.p + n * sizeof(tcrc_desc));
   for (uint64_t b0 = 0; b0 < n; b0 += kLongLdsBuffers) {
@@ -246,7 +234,7 @@ extern "C" int tcrc_dev_extend_long(tcrc_ctx* ctx, const void* d_base, const tcr
     p.out = d_out + b0;
     if (int rc = run_segments(ctx, p, la, stream)) return rc;
   }
-  guard.armed = false;
+  guard.dismiss();
   HIP_TRY(hipStreamSynchronize(s));
   return TCRC_OK;
 }

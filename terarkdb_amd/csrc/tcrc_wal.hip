@@ -196,6 +196,7 @@ extern "C" int tcrc_dev_wal_frame(tcrc_ctx* ctx, const void* d_src, const tcrc_d
   const size_t frag_bytes = frags.size() * sizeof(Frag);
   const size_t span_off = (frag_bytes + 255) & ~(size_t)255;
   if (int rc = scratch_reserve(ctx, &ctx->wal_frags, span_off + frags.size() * sizeof(tcrc_desc))) return rc;
+  StreamGuard guard(s);  // `frags` must not go away with its copy in flight
   HIP_TRY(hipMemcpyAsync(ctx->wal_frags.p, frags.data(), frag_bytes, hipMemcpyHostToDevice, s));
   FrameParams f{};
   f.src = (const uint8_t*)d_src;
@@ -214,6 +215,7 @@ extern "C" int tcrc_dev_wal_frame(tcrc_ctx* ctx, const void* d_src, const tcrc_d
   p.uniform_suffix = -1;
   p.flags = TCRC_F_MASK | kFlagStampBefore;  // zero runs have empty spans, which the kernel does not stamp
   if (int rc = run_batch(ctx, p, stream)) return rc;
+  guard.dismiss();
   HIP_TRY(hipStreamSynchronize(s));  // the piece list was copied from pageable memory
   if (h_written) *h_written = total;
   if (block_offset_out) *block_offset_out = bo;

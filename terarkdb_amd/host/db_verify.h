@@ -18,6 +18,8 @@ namespace terarkdb_amd {
 
 struct DbVerifyReport {
   uint64_t table_files = 0, table_files_declined = 0, table_blocks = 0, table_bytes_covered = 0;
+  // log_bad_records counts EVERY physical record whose checksum fails; the reference's reader stops looking at a
+  // 32 KiB block at its first bad record (db/log_reader.cc:391-397), so it can meet fewer.
   uint64_t log_files = 0, log_bytes = 0, log_records = 0, log_bad_records = 0;
   std::string first_bad_file;  // the file the returned status is about
   std::vector<std::string> log_notes;  // one line per log file with a bad record or a torn tail
