@@ -85,6 +85,7 @@ typedef struct tcrc_stats {
   uint64_t log_bytes;      /* and their bytes */
   uint64_t long_calls;     /* tcrc_dev_extend_long calls */
   uint64_t long_bytes;     /* and the bytes they covered */
+  uint64_t host_lanes;     /* lanes (stream + staging) the context has created for concurrent host calls: not reset */
 } tcrc_stats;
 int tcrc_get_stats(tcrc_ctx* ctx, tcrc_stats* out);
 int tcrc_reset_stats(tcrc_ctx* ctx);
@@ -229,7 +230,10 @@ int tcrc_dev_counts_reset(tcrc_ctx* ctx, uint64_t* d_counts, void* stream);
 /* The reference's path starts and ends in host memory (log file buffers, blocks read through
  * env/io_posix.cc).  These entry points take host pointers, copy the bytes to the GPU, run the
  * device path above and copy the results back; they return when the results are in place.
- * One such call runs at a time per context (they share the context's staging memory). */
+ * Calls from different threads on one context run side by side: each takes one of the context's lanes (a
+ * stream, staging memory on the device and a pinned block for small calls), of which a context creates up to
+ * 16 on demand - the reference calls this path from several flush and compaction threads at once
+ * (table/block_based_table_builder.cc:580, db/db_impl_write.cc:844-854).  Further callers wait for a lane. */
 void* tcrc_host_alloc(tcrc_ctx* ctx, size_t bytes); /* pinned memory: copies from it run at link rate */
 void tcrc_host_free(tcrc_ctx* ctx, void* p);
 int tcrc_host_batch_stamp(tcrc_ctx* ctx, const void* h_base, uint64_t base_bytes, const tcrc_desc* h_desc, uint64_t n,

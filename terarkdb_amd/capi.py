@@ -33,7 +33,7 @@ class WalBlock(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("batch_launches", "batch_buffers", "host_calls", "host_bytes_in", "host_nanos",
-                                          "log_images", "log_bytes", "long_calls", "long_bytes")]
+                                          "log_images", "log_bytes", "long_calls", "long_bytes", "host_lanes")]
 
 
 class Desc(C.Structure):

@@ -1115,14 +1115,18 @@ int tcrc_shutdown(tcrc_ctx* ctx) {
     if (ctx->d_tab_aux[gi]) (void)hipFree(ctx->d_tab_aux[gi]);
   }
   for (tcrc_scratch* s : {&ctx->wal_misc, &ctx->wal_list_counts,
-                          &ctx->wal_list_first, &ctx->wal_list_temp, &ctx->wal_frags, &ctx->host_records,
-                          &ctx->host_data, &ctx->host_desc, &ctx->host_out, &ctx->host_aux, &ctx->host_blocks,
+                          &ctx->wal_list_first, &ctx->wal_list_temp, &ctx->wal_frags,
                           &ctx->long_in, &ctx->long_acc})
     scratch_release(s);
-  if (ctx->host_stream) (void)hipStreamDestroy(ctx->host_stream);
+  for (tcrc_lane* l : ctx->lanes) {
+    for (tcrc_scratch* s : {&l->data, &l->desc, &l->out, &l->aux, &l->blocks, &l->records}) scratch_release(s);
+    if (l->stream) (void)hipStreamDestroy(l->stream);
+    if (l->zc) (void)hipHostFree(l->zc);
+    delete l;
+  }
+  ctx->lanes.clear();
   for (auto& e : ctx->pin_free) (void)hipHostFree(e.first);
   if (ctx->stage_ring) (void)hipHostFree(ctx->stage_ring);
-  if (ctx->zc) (void)hipHostFree(ctx->zc);
   if (ctx->long_pin) (void)hipHostFree(ctx->long_pin);
   if (ctx->wal_pin) (void)hipHostFree(ctx->wal_pin);
   for (hipEvent_t ev : ctx->stage_done)
@@ -1142,6 +1146,10 @@ int tcrc_get_stats(tcrc_ctx* ctx, tcrc_stats* out) {
   out->log_bytes = ctx->st_log_bytes.load();
   out->long_calls = ctx->st_long_calls.load();
   out->long_bytes = ctx->st_long_bytes.load();
+  {
+    std::lock_guard<std::mutex> lock(ctx->lanes_mu);
+    out->host_lanes = ctx->lanes.size();
+  }
   return TCRC_OK;
 }
 

@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include <atomic>
+#include <functional>
 #include <string>
 #include <thread>
 #include <vector>
@@ -19,10 +20,39 @@ using namespace tcrc_internal;
 
 namespace {
 
-int host_begin(tcrc_ctx* ctx) {  // the caller has made the context's GPU current
-  if (!ctx->host_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->host_stream, hipStreamNonBlocking));
+int host_begin(tcrc_lane* L) {  // the caller has made the context's GPU current
+  if (!L->stream) HIP_TRY(hipStreamCreateWithFlags(&L->stream, hipStreamNonBlocking));
   return TCRC_OK;
 }
+
+// Leases a lane of the context for one host call: a free one if there is one, a new one while fewer than
+// kMaxLanes exist, else the call waits for the lane its thread hashes to.
+struct LaneLease {
+  tcrc_lane* lane = nullptr;
+  explicit LaneLease(tcrc_ctx* ctx) {
+    size_t pick = 0;
+    {
+      std::lock_guard<std::mutex> lock(ctx->lanes_mu);
+      for (tcrc_lane* l : ctx->lanes)
+        if (l->mu.try_lock()) {
+          lane = l;
+          return;
+        }
+      if (ctx->lanes.size() < (size_t)tcrc_ctx::kMaxLanes) {
+        lane = new tcrc_lane();
+        lane->mu.lock();
+        ctx->lanes.push_back(lane);
+        return;
+      }
+      pick = std::hash<std::thread::id>()(std::this_thread::get_id()) % ctx->lanes.size();
+      lane = ctx->lanes[pick];
+    }
+    lane->mu.lock();
+  }
+  ~LaneLease() { lane->mu.unlock(); }
+  LaneLease(const LaneLease&) = delete;
+  void operator=(const LaneLease&) = delete;
+};
 
 // Layout of the zero-copy block
 constexpr size_t kZcDescOff = tcrc_ctx::kZcData;
@@ -34,9 +64,8 @@ constexpr size_t kZcBytes = kZcOkOff + tcrc_ctx::kZcMaxItems;
 // Above this many input bytes a copy to HBM pays for itself (the kernel reads host memory at link speed).
 constexpr size_t kZcMaxInput = (size_t)1 << 20;
 
-int zc_begin(tcrc_ctx* ctx) {
-  if (!ctx->zc)
-    HIP_TRY(hipHostMalloc((void**)&ctx->zc, kZcBytes, hipHostMallocMapped | hipHostMallocCoherent));
+int zc_begin(tcrc_lane* L) {
+  if (!L->zc) HIP_TRY(hipHostMalloc((void**)&L->zc, kZcBytes, hipHostMallocMapped | hipHostMallocCoherent));
   return TCRC_OK;
 }
 
@@ -56,7 +85,8 @@ bool is_pinned(const void* p, const void** dev = nullptr) {
 // Copies pageable host memory to the device through a ring of pinned slots: several host threads
 // fill slots while the copy engine drains them, which roughly doubles the rate of a plain
 // hipMemcpy from pageable memory (the runtime stages through one thread).
-int staged_upload(tcrc_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
+int staged_upload(tcrc_ctx* ctx, tcrc_lane* L, void* d_dst, const void* h_src, size_t bytes) {
+  std::lock_guard<std::mutex> ring_lock(ctx->stage_mu);
   constexpr int K = tcrc_ctx::kStageSlots;
   constexpr size_t S = tcrc_ctx::kStageSlotBytes;
   if (!ctx->stage_ring) {
@@ -106,8 +136,8 @@ int staged_upload(tcrc_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
       if (failed.load()) break; else std::this_thread::yield();
     if (failed.load()) break;
     const size_t off = i * S, len = bytes - off < S ? bytes - off : S;
-    err = hipMemcpyAsync((char*)d_dst + off, ctx->stage_ring + (i % K) * S, len, hipMemcpyHostToDevice, ctx->host_stream);
-    if (err == hipSuccess) err = hipEventRecord(ctx->stage_done[i % K], ctx->host_stream);
+    err = hipMemcpyAsync((char*)d_dst + off, ctx->stage_ring + (i % K) * S, len, hipMemcpyHostToDevice, L->stream);
+    if (err == hipSuccess) err = hipEventRecord(ctx->stage_done[i % K], L->stream);
     if (err == hipSuccess) ctx->stage_recorded[i % K] = true;  // read by later uploads only
     issued[i].store(1, std::memory_order_release);
   }
@@ -153,29 +183,29 @@ bool wants_long_route(const tcrc_desc* d, uint64_t n, const uint8_t* h_suffix) {
   return false;
 }
 
-int upload(tcrc_ctx* ctx, tcrc_scratch* s, const void* h, size_t bytes, size_t slack);
+int upload(tcrc_ctx* ctx, tcrc_lane* L, tcrc_scratch* s, const void* h, size_t bytes, size_t slack);
 
-// Plain CRCs of the descriptors' spans through the long-buffer path, into h_crc.  Caller holds host_mu.
-int long_route(tcrc_ctx* ctx, const void* h_base, uint64_t base_bytes, const tcrc_desc* h_desc, uint64_t n,
+// Plain CRCs of the descriptors' spans through the long-buffer path, into h_crc.  The caller holds lane L.
+int long_route(tcrc_ctx* ctx, tcrc_lane* L, const void* h_base, uint64_t base_bytes, const tcrc_desc* h_desc, uint64_t n,
                uint32_t* h_crc) {
   // (n <= kZcMaxItems here: the results land in the zero-copy block, so the call that returns with them
   // complete is the only synchronisation)
-  if (int rc = zc_begin(ctx)) return rc;
-  if (int rc = upload(ctx, &ctx->host_data, h_base, base_bytes, 64)) return rc;
-  if (int rc = tcrc_dev_extend_long(ctx, ctx->host_data.p, h_desc, n, 0, (uint32_t*)(ctx->zc + kZcOutOff),
-                                    ctx->host_stream)) {
-    (void)hipStreamSynchronize(ctx->host_stream);  // the upload may still be reading the caller's memory
+  if (int rc = zc_begin(L)) return rc;
+  if (int rc = upload(ctx, L, &L->data, h_base, base_bytes, 64)) return rc;
+  if (int rc = tcrc_dev_extend_long(ctx, L->data.p, h_desc, n, 0, (uint32_t*)(L->zc + kZcOutOff),
+                                    L->stream)) {
+    (void)hipStreamSynchronize(L->stream);  // the upload may still be reading the caller's memory
     return rc;
   }
-  memcpy(h_crc, ctx->zc + kZcOutOff, n * 4);
+  memcpy(h_crc, L->zc + kZcOutOff, n * 4);
   return TCRC_OK;
 }
 
-int upload(tcrc_ctx* ctx, tcrc_scratch* s, const void* h, size_t bytes, size_t slack = 64) {
+int upload(tcrc_ctx* ctx, tcrc_lane* L, tcrc_scratch* s, const void* h, size_t bytes, size_t slack = 64) {
   if (int rc = scratch_reserve(ctx, s, bytes + slack)) return rc;
   ctx->st_host_bytes_in.fetch_add(bytes, std::memory_order_relaxed);
-  if (bytes >= ((size_t)16 << 20) && !is_pinned(h)) return staged_upload(ctx, s->p, h, bytes);
-  if (bytes) HIP_TRY(hipMemcpyAsync(s->p, h, bytes, hipMemcpyHostToDevice, ctx->host_stream));
+  if (bytes >= ((size_t)16 << 20) && !is_pinned(h)) return staged_upload(ctx, L, s->p, h, bytes);
+  if (bytes) HIP_TRY(hipMemcpyAsync(s->p, h, bytes, hipMemcpyHostToDevice, L->stream));
   return TCRC_OK;
 }
 
@@ -245,13 +275,14 @@ int tcrc_host_batch_stamp(tcrc_ctx* ctx, const void* h_base, uint64_t base_bytes
   if (flags & TCRC_F_STORE_AFTER) return fail(TCRC_ERR_INVALID, "host entry points return the values: nothing to store into");
   if (int rc = check_descs(h_desc, n, base_bytes, 0, false)) return rc;
   HostCallTimer timer(ctx);
-  std::lock_guard<std::mutex> lock(ctx->host_mu);
+  LaneLease lease(ctx);
+  tcrc_lane* const L = lease.lane;
   TCRC_DEVICE_SCOPE(ctx);
-  if (int rc = host_begin(ctx)) return rc;
-  StreamGuard guard(ctx->host_stream);  // an error return must not leave copies from the caller's memory in flight
+  if (int rc = host_begin(L)) return rc;
+  StreamGuard guard(L->stream);  // an error return must not leave copies from the caller's memory in flight
   if (wants_long_route(h_desc, n, h_suffix)) {
     if (int rc = check_flags_host(flags, TCRC_F_MASK)) return rc;
-    if (int rc = long_route(ctx, h_base, base_bytes, h_desc, n, h_out)) return rc;
+    if (int rc = long_route(ctx, L, h_base, base_bytes, h_desc, n, h_out)) return rc;
     guard.dismiss();  // long_route returns with the stream drained
     if (flags & TCRC_F_MASK)
       for (uint64_t i = 0; i < n; ++i) h_out[i] = tcrc_mask(h_out[i]);
@@ -260,35 +291,35 @@ int tcrc_host_batch_stamp(tcrc_ctx* ctx, const void* h_base, uint64_t base_bytes
   if (zero_copy_fits(h_base, base_bytes, n)) {
     // Small batch: no copies.  The kernel reads the bytes where they are (pinned memory) or from the bounce
     // area, takes its descriptors from the zero-copy block and writes the results there.
-    if (int rc = zc_begin(ctx)) return rc;
+    if (int rc = zc_begin(L)) return rc;
     const void* base = nullptr;
     if (!is_pinned(h_base, &base)) {
-      memcpy(ctx->zc, h_base, base_bytes);
-      base = ctx->zc;
+      memcpy(L->zc, h_base, base_bytes);
+      base = L->zc;
     }
-    memcpy(ctx->zc + kZcDescOff, h_desc, n * sizeof(tcrc_desc));
-    if (h_suffix) memcpy(ctx->zc + kZcSuffixOff, h_suffix, n);
-    if (int rc = tcrc_dev_batch_stamp(ctx, base, (const tcrc_desc*)(ctx->zc + kZcDescOff), n,
-                                      h_suffix ? (const uint8_t*)(ctx->zc + kZcSuffixOff) : nullptr, flags,
-                                      (uint32_t*)(ctx->zc + kZcOutOff), ctx->host_stream))
+    memcpy(L->zc + kZcDescOff, h_desc, n * sizeof(tcrc_desc));
+    if (h_suffix) memcpy(L->zc + kZcSuffixOff, h_suffix, n);
+    if (int rc = tcrc_dev_batch_stamp(ctx, base, (const tcrc_desc*)(L->zc + kZcDescOff), n,
+                                      h_suffix ? (const uint8_t*)(L->zc + kZcSuffixOff) : nullptr, flags,
+                                      (uint32_t*)(L->zc + kZcOutOff), L->stream))
       return rc;
     guard.dismiss();
-    HIP_TRY(hipStreamSynchronize(ctx->host_stream));
-    memcpy(h_out, ctx->zc + kZcOutOff, n * 4);
+    HIP_TRY(hipStreamSynchronize(L->stream));
+    memcpy(h_out, L->zc + kZcOutOff, n * 4);
     return TCRC_OK;
   }
-  if (int rc = upload(ctx, &ctx->host_data, h_base, base_bytes)) return rc;
-  if (int rc = upload(ctx, &ctx->host_desc, h_desc, n * sizeof(tcrc_desc))) return rc;
+  if (int rc = upload(ctx, L, &L->data, h_base, base_bytes)) return rc;
+  if (int rc = upload(ctx, L, &L->desc, h_desc, n * sizeof(tcrc_desc))) return rc;
   if (h_suffix)
-    if (int rc = upload(ctx, &ctx->host_aux, h_suffix, n)) return rc;
-  if (int rc = scratch_reserve(ctx, &ctx->host_out, n * 4)) return rc;
-  if (int rc = tcrc_dev_batch_stamp(ctx, ctx->host_data.p, (const tcrc_desc*)ctx->host_desc.p, n,
-                                    h_suffix ? (const uint8_t*)ctx->host_aux.p : nullptr, flags,
-                                    (uint32_t*)ctx->host_out.p, ctx->host_stream))
+    if (int rc = upload(ctx, L, &L->aux, h_suffix, n)) return rc;
+  if (int rc = scratch_reserve(ctx, &L->out, n * 4)) return rc;
+  if (int rc = tcrc_dev_batch_stamp(ctx, L->data.p, (const tcrc_desc*)L->desc.p, n,
+                                    h_suffix ? (const uint8_t*)L->aux.p : nullptr, flags,
+                                    (uint32_t*)L->out.p, L->stream))
     return rc;
-  HIP_TRY(hipMemcpyAsync(h_out, ctx->host_out.p, n * 4, hipMemcpyDeviceToHost, ctx->host_stream));
+  HIP_TRY(hipMemcpyAsync(h_out, L->out.p, n * 4, hipMemcpyDeviceToHost, L->stream));
   guard.dismiss();
-  HIP_TRY(hipStreamSynchronize(ctx->host_stream));
+  HIP_TRY(hipStreamSynchronize(L->stream));
   return TCRC_OK;
 }
 
@@ -304,19 +335,20 @@ int tcrc_host_blocks_stamp(tcrc_ctx* ctx, const void* h_base, uint64_t n_blocks,
   if (n_blocks > 1 && (n_blocks - 1) > (~0ull - block_len) / stride)
     return fail(TCRC_ERR_INVALID, "n_blocks * stride overflows");
   HostCallTimer timer(ctx);
-  std::lock_guard<std::mutex> lock(ctx->host_mu);
+  LaneLease lease(ctx);
+  tcrc_lane* const L = lease.lane;
   TCRC_DEVICE_SCOPE(ctx);
-  if (int rc = host_begin(ctx)) return rc;
-  StreamGuard guard(ctx->host_stream);  // an error return must not leave copies from the caller's memory in flight
+  if (int rc = host_begin(L)) return rc;
+  StreamGuard guard(L->stream);  // an error return must not leave copies from the caller's memory in flight
   const uint64_t bytes = (n_blocks - 1) * stride + block_len;
-  if (int rc = upload(ctx, &ctx->host_data, h_base, bytes)) return rc;
-  if (int rc = scratch_reserve(ctx, &ctx->host_out, n_blocks * 4)) return rc;
-  if (int rc = tcrc_dev_blocks_stamp(ctx, ctx->host_data.p, n_blocks, block_len, stride, init, suffix_byte, nullptr,
-                                     flags, (uint32_t*)ctx->host_out.p, ctx->host_stream))
+  if (int rc = upload(ctx, L, &L->data, h_base, bytes)) return rc;
+  if (int rc = scratch_reserve(ctx, &L->out, n_blocks * 4)) return rc;
+  if (int rc = tcrc_dev_blocks_stamp(ctx, L->data.p, n_blocks, block_len, stride, init, suffix_byte, nullptr,
+                                     flags, (uint32_t*)L->out.p, L->stream))
     return rc;
-  HIP_TRY(hipMemcpyAsync(h_out, ctx->host_out.p, n_blocks * 4, hipMemcpyDeviceToHost, ctx->host_stream));
+  HIP_TRY(hipMemcpyAsync(h_out, L->out.p, n_blocks * 4, hipMemcpyDeviceToHost, L->stream));
   guard.dismiss();
-  HIP_TRY(hipStreamSynchronize(ctx->host_stream));
+  HIP_TRY(hipStreamSynchronize(L->stream));
   return TCRC_OK;
 }
 
@@ -334,16 +366,17 @@ int tcrc_host_batch_verify(tcrc_ctx* ctx, const void* h_base, uint64_t base_byte
                            (flags & TCRC_F_EXPECT_BEFORE) != 0))
     return rc;
   HostCallTimer timer(ctx);
-  std::lock_guard<std::mutex> lock(ctx->host_mu);
+  LaneLease lease(ctx);
+  tcrc_lane* const L = lease.lane;
   TCRC_DEVICE_SCOPE(ctx);
-  if (int rc = host_begin(ctx)) return rc;
-  StreamGuard guard(ctx->host_stream);  // an error return must not leave copies from the caller's memory in flight
+  if (int rc = host_begin(L)) return rc;
+  StreamGuard guard(L->stream);  // an error return must not leave copies from the caller's memory in flight
   if (wants_long_route(h_desc, n, h_suffix)) {
     if (int rc = check_flags_host(flags, TCRC_F_MASK | TCRC_F_EXPECT_AFTER | TCRC_F_EXPECT_BEFORE)) return rc;
     if (!h_expected && !(flags & (TCRC_F_EXPECT_AFTER | TCRC_F_EXPECT_BEFORE)))
       return fail(TCRC_ERR_INVALID, "verify needs h_expected or an in-image expectation flag");
     std::vector<uint32_t> crc(n);
-    if (int rc = long_route(ctx, h_base, base_bytes, h_desc, n, crc.data())) return rc;
+    if (int rc = long_route(ctx, L, h_base, base_bytes, h_desc, n, crc.data())) return rc;
     guard.dismiss();  // long_route returns with the stream drained
     for (uint64_t i = 0; i < n; ++i) {
       const uint32_t masked = tcrc_mask(crc[i]);
@@ -368,26 +401,26 @@ int tcrc_host_batch_verify(tcrc_ctx* ctx, const void* h_base, uint64_t base_byte
     // reads the bytes where they lie or from the bounce area and leaves values and verdicts in the
     // zero-copy block; the three counters are derived from the verdicts here, so that the kernel's own
     // counter updates (atomics) stay in device memory.
-    if (int rc = zc_begin(ctx)) return rc;
-    if (int rc = scratch_reserve(ctx, &ctx->host_aux, 64)) return rc;
+    if (int rc = zc_begin(L)) return rc;
+    if (int rc = scratch_reserve(ctx, &L->aux, 64)) return rc;
     const void* base = nullptr;
     if (!is_pinned(h_base, &base)) {
-      memcpy(ctx->zc, h_base, base_bytes);
-      base = ctx->zc;
+      memcpy(L->zc, h_base, base_bytes);
+      base = L->zc;
     }
-    memcpy(ctx->zc + kZcDescOff, h_desc, n * sizeof(tcrc_desc));
-    if (h_suffix) memcpy(ctx->zc + kZcSuffixOff, h_suffix, n);
-    if (h_expected) memcpy(ctx->zc + kZcExpectedOff, h_expected, n * 4);
-    const uint8_t* ok = (const uint8_t*)(ctx->zc + kZcOkOff);
-    if (int rc = tcrc_dev_batch_verify(ctx, base, (const tcrc_desc*)(ctx->zc + kZcDescOff), n,
-                                       h_suffix ? (const uint8_t*)(ctx->zc + kZcSuffixOff) : nullptr, flags,
-                                       h_expected ? (const uint32_t*)(ctx->zc + kZcExpectedOff) : nullptr,
-                                       (uint32_t*)(ctx->zc + kZcOutOff), (uint8_t*)(ctx->zc + kZcOkOff),
-                                       (uint64_t*)ctx->host_aux.p, ctx->host_stream))
+    memcpy(L->zc + kZcDescOff, h_desc, n * sizeof(tcrc_desc));
+    if (h_suffix) memcpy(L->zc + kZcSuffixOff, h_suffix, n);
+    if (h_expected) memcpy(L->zc + kZcExpectedOff, h_expected, n * 4);
+    const uint8_t* ok = (const uint8_t*)(L->zc + kZcOkOff);
+    if (int rc = tcrc_dev_batch_verify(ctx, base, (const tcrc_desc*)(L->zc + kZcDescOff), n,
+                                       h_suffix ? (const uint8_t*)(L->zc + kZcSuffixOff) : nullptr, flags,
+                                       h_expected ? (const uint32_t*)(L->zc + kZcExpectedOff) : nullptr,
+                                       (uint32_t*)(L->zc + kZcOutOff), (uint8_t*)(L->zc + kZcOkOff),
+                                       (uint64_t*)L->aux.p, L->stream))
       return rc;
     guard.dismiss();
-    HIP_TRY(hipStreamSynchronize(ctx->host_stream));
-    if (h_out) memcpy(h_out, ctx->zc + kZcOutOff, n * 4);
+    HIP_TRY(hipStreamSynchronize(L->stream));
+    if (h_out) memcpy(h_out, L->zc + kZcOutOff, n * 4);
     if (h_ok) memcpy(h_ok, ok, n);
     for (uint64_t i = 0; i < n; ++i)
       if (!ok[i]) {
@@ -396,27 +429,27 @@ int tcrc_host_batch_verify(tcrc_ctx* ctx, const void* h_base, uint64_t base_byte
     h_counts[TCRC_CNT_CHECKED] = n;
     return TCRC_OK;
   }
-  if (int rc = upload(ctx, &ctx->host_data, h_base, base_bytes)) return rc;
-  if (int rc = upload(ctx, &ctx->host_desc, h_desc, n * sizeof(tcrc_desc))) return rc;
+  if (int rc = upload(ctx, L, &L->data, h_base, base_bytes)) return rc;
+  if (int rc = upload(ctx, L, &L->desc, h_desc, n * sizeof(tcrc_desc))) return rc;
   // host_aux layout: [counts 3 x u64][suffix n][pad][expected n x u32][ok n]
   const size_t off_suffix = 32, off_expected = (off_suffix + n + 15) & ~(size_t)15, off_ok = off_expected + n * 4;
-  if (int rc = scratch_reserve(ctx, &ctx->host_aux, off_ok + n + 64)) return rc;
-  uint8_t* aux = (uint8_t*)ctx->host_aux.p;
-  if (h_suffix) HIP_TRY(hipMemcpyAsync(aux + off_suffix, h_suffix, n, hipMemcpyHostToDevice, ctx->host_stream));
+  if (int rc = scratch_reserve(ctx, &L->aux, off_ok + n + 64)) return rc;
+  uint8_t* aux = (uint8_t*)L->aux.p;
+  if (h_suffix) HIP_TRY(hipMemcpyAsync(aux + off_suffix, h_suffix, n, hipMemcpyHostToDevice, L->stream));
   if (h_expected)
-    HIP_TRY(hipMemcpyAsync(aux + off_expected, h_expected, n * 4, hipMemcpyHostToDevice, ctx->host_stream));
-  if (int rc = scratch_reserve(ctx, &ctx->host_out, n * 4)) return rc;
-  if (int rc = tcrc_dev_counts_reset(ctx, (uint64_t*)aux, ctx->host_stream)) return rc;
-  if (int rc = tcrc_dev_batch_verify(ctx, ctx->host_data.p, (const tcrc_desc*)ctx->host_desc.p, n,
+    HIP_TRY(hipMemcpyAsync(aux + off_expected, h_expected, n * 4, hipMemcpyHostToDevice, L->stream));
+  if (int rc = scratch_reserve(ctx, &L->out, n * 4)) return rc;
+  if (int rc = tcrc_dev_counts_reset(ctx, (uint64_t*)aux, L->stream)) return rc;
+  if (int rc = tcrc_dev_batch_verify(ctx, L->data.p, (const tcrc_desc*)L->desc.p, n,
                                      h_suffix ? aux + off_suffix : nullptr, flags,
                                      h_expected ? (const uint32_t*)(aux + off_expected) : nullptr,
-                                     (uint32_t*)ctx->host_out.p, aux + off_ok, (uint64_t*)aux, ctx->host_stream))
+                                     (uint32_t*)L->out.p, aux + off_ok, (uint64_t*)aux, L->stream))
     return rc;
-  if (h_out) HIP_TRY(hipMemcpyAsync(h_out, ctx->host_out.p, n * 4, hipMemcpyDeviceToHost, ctx->host_stream));
-  if (h_ok) HIP_TRY(hipMemcpyAsync(h_ok, aux + off_ok, n, hipMemcpyDeviceToHost, ctx->host_stream));
-  HIP_TRY(hipMemcpyAsync(h_counts, aux, 24, hipMemcpyDeviceToHost, ctx->host_stream));
+  if (h_out) HIP_TRY(hipMemcpyAsync(h_out, L->out.p, n * 4, hipMemcpyDeviceToHost, L->stream));
+  if (h_ok) HIP_TRY(hipMemcpyAsync(h_ok, aux + off_ok, n, hipMemcpyDeviceToHost, L->stream));
+  HIP_TRY(hipMemcpyAsync(h_counts, aux, 24, hipMemcpyDeviceToHost, L->stream));
   guard.dismiss();
-  HIP_TRY(hipStreamSynchronize(ctx->host_stream));
+  HIP_TRY(hipStreamSynchronize(L->stream));
   return TCRC_OK;
 }
 
@@ -440,25 +473,26 @@ int tcrc_host_wal_verify_part(tcrc_ctx* ctx, const void* h_part, uint64_t size, 
   if (size == 0) return TCRC_OK;
   if (!h_part || !h_blocks) return fail(TCRC_ERR_INVALID, "null argument");
   HostCallTimer timer(ctx);
-  std::lock_guard<std::mutex> lock(ctx->host_mu);
+  LaneLease lease(ctx);
+  tcrc_lane* const L = lease.lane;
   TCRC_DEVICE_SCOPE(ctx);
-  if (int rc = host_begin(ctx)) return rc;
-  StreamGuard guard(ctx->host_stream);  // an error return must not leave copies from the caller's memory in flight
+  if (int rc = host_begin(L)) return rc;
+  StreamGuard guard(L->stream);  // an error return must not leave copies from the caller's memory in flight
   const uint64_t nblocks = (size + 32767) / 32768;
-  if (int rc = upload(ctx, &ctx->host_data, h_part, size)) return rc;
-  if (int rc = scratch_reserve(ctx, &ctx->host_blocks, nblocks * sizeof(tcrc_wal_block))) return rc;
-  if (int rc = scratch_reserve(ctx, &ctx->host_aux, 64)) return rc;
-  if (int rc = tcrc_dev_counts_reset(ctx, (uint64_t*)ctx->host_aux.p, ctx->host_stream)) return rc;
-  if (int rc = tcrc_dev_wal_verify_part(ctx, ctx->host_data.p, size, log_number, first_block, more_follows,
-                                        (tcrc_wal_block*)ctx->host_blocks.p, (uint64_t*)ctx->host_aux.p, h_records,
-                                        ctx->host_stream))
+  if (int rc = upload(ctx, L, &L->data, h_part, size)) return rc;
+  if (int rc = scratch_reserve(ctx, &L->blocks, nblocks * sizeof(tcrc_wal_block))) return rc;
+  if (int rc = scratch_reserve(ctx, &L->aux, 64)) return rc;
+  if (int rc = tcrc_dev_counts_reset(ctx, (uint64_t*)L->aux.p, L->stream)) return rc;
+  if (int rc = tcrc_dev_wal_verify_part(ctx, L->data.p, size, log_number, first_block, more_follows,
+                                        (tcrc_wal_block*)L->blocks.p, (uint64_t*)L->aux.p, h_records,
+                                        L->stream))
     return rc;
-  HIP_TRY(hipMemcpyAsync(h_blocks, ctx->host_blocks.p, nblocks * sizeof(tcrc_wal_block), hipMemcpyDeviceToHost,
-                         ctx->host_stream));
+  HIP_TRY(hipMemcpyAsync(h_blocks, L->blocks.p, nblocks * sizeof(tcrc_wal_block), hipMemcpyDeviceToHost,
+                         L->stream));
   uint64_t part_counts[TCRC_CNT_WORDS] = {0, ~0ull, 0};
-  if (h_counts) HIP_TRY(hipMemcpyAsync(part_counts, ctx->host_aux.p, 24, hipMemcpyDeviceToHost, ctx->host_stream));
+  if (h_counts) HIP_TRY(hipMemcpyAsync(part_counts, L->aux.p, 24, hipMemcpyDeviceToHost, L->stream));
   guard.dismiss();
-  HIP_TRY(hipStreamSynchronize(ctx->host_stream));
+  HIP_TRY(hipStreamSynchronize(L->stream));
   if (h_counts) {
     h_counts[TCRC_CNT_MISMATCH] += part_counts[TCRC_CNT_MISMATCH];
     if (part_counts[TCRC_CNT_FIRST_BAD] < h_counts[TCRC_CNT_FIRST_BAD])
@@ -475,32 +509,33 @@ int tcrc_host_wal_list(tcrc_ctx* ctx, const void* h_img, uint64_t size, uint64_t
   if (size == 0) return TCRC_OK;
   if (!h_img || (capacity && !h_records)) return fail(TCRC_ERR_INVALID, "null argument");
   HostCallTimer timer(ctx);
-  std::lock_guard<std::mutex> lock(ctx->host_mu);
+  LaneLease lease(ctx);
+  tcrc_lane* const L = lease.lane;
   TCRC_DEVICE_SCOPE(ctx);
-  if (int rc = host_begin(ctx)) return rc;
-  StreamGuard guard(ctx->host_stream);  // an error return must not leave copies from the caller's memory in flight
+  if (int rc = host_begin(L)) return rc;
+  StreamGuard guard(L->stream);  // an error return must not leave copies from the caller's memory in flight
   const uint64_t nblocks = (size + 32767) / 32768;
-  if (int rc = upload(ctx, &ctx->host_data, h_img, size)) return rc;
-  if (int rc = scratch_reserve(ctx, &ctx->host_blocks, nblocks * sizeof(tcrc_wal_block))) return rc;
-  if (int rc = scratch_reserve(ctx, &ctx->host_aux, 64)) return rc;
-  if (int rc = scratch_reserve(ctx, &ctx->host_records, (capacity ? capacity : 1) * sizeof(tcrc_wal_record))) return rc;
-  if (int rc = tcrc_dev_counts_reset(ctx, (uint64_t*)ctx->host_aux.p, ctx->host_stream)) return rc;
-  if (int rc = tcrc_dev_wal_verify(ctx, ctx->host_data.p, size, log_number, (tcrc_wal_block*)ctx->host_blocks.p,
-                                   (uint64_t*)ctx->host_aux.p, nullptr, ctx->host_stream))
+  if (int rc = upload(ctx, L, &L->data, h_img, size)) return rc;
+  if (int rc = scratch_reserve(ctx, &L->blocks, nblocks * sizeof(tcrc_wal_block))) return rc;
+  if (int rc = scratch_reserve(ctx, &L->aux, 64)) return rc;
+  if (int rc = scratch_reserve(ctx, &L->records, (capacity ? capacity : 1) * sizeof(tcrc_wal_record))) return rc;
+  if (int rc = tcrc_dev_counts_reset(ctx, (uint64_t*)L->aux.p, L->stream)) return rc;
+  if (int rc = tcrc_dev_wal_verify(ctx, L->data.p, size, log_number, (tcrc_wal_block*)L->blocks.p,
+                                   (uint64_t*)L->aux.p, nullptr, L->stream))
     return rc;
   uint64_t total = 0;
-  if (int rc = tcrc_dev_wal_list(ctx, ctx->host_data.p, size, log_number, (const tcrc_wal_block*)ctx->host_blocks.p,
-                                 (tcrc_wal_record*)ctx->host_records.p, capacity, &total, ctx->host_stream))
+  if (int rc = tcrc_dev_wal_list(ctx, L->data.p, size, log_number, (const tcrc_wal_block*)L->blocks.p,
+                                 (tcrc_wal_record*)L->records.p, capacity, &total, L->stream))
     return rc;
   if (h_blocks)
-    HIP_TRY(hipMemcpyAsync(h_blocks, ctx->host_blocks.p, nblocks * sizeof(tcrc_wal_block), hipMemcpyDeviceToHost,
-                           ctx->host_stream));
+    HIP_TRY(hipMemcpyAsync(h_blocks, L->blocks.p, nblocks * sizeof(tcrc_wal_block), hipMemcpyDeviceToHost,
+                           L->stream));
   const uint64_t n_out = total < capacity ? total : capacity;
   if (n_out)
-    HIP_TRY(hipMemcpyAsync(h_records, ctx->host_records.p, n_out * sizeof(tcrc_wal_record), hipMemcpyDeviceToHost,
-                           ctx->host_stream));
+    HIP_TRY(hipMemcpyAsync(h_records, L->records.p, n_out * sizeof(tcrc_wal_record), hipMemcpyDeviceToHost,
+                           L->stream));
   guard.dismiss();
-  HIP_TRY(hipStreamSynchronize(ctx->host_stream));
+  HIP_TRY(hipStreamSynchronize(L->stream));
   if (h_count) *h_count = total;
   return TCRC_OK;
 }
@@ -512,47 +547,48 @@ int tcrc_extend(tcrc_ctx* ctx, uint32_t init, const void* h_data, size_t n, uint
   if (n == 0) return TCRC_OK;
   if (!h_data) return fail(TCRC_ERR_INVALID, "null argument");
   HostCallTimer timer(ctx);
-  std::lock_guard<std::mutex> lock(ctx->host_mu);
+  LaneLease lease(ctx);
+  tcrc_lane* const L = lease.lane;
   TCRC_DEVICE_SCOPE(ctx);
-  if (int rc = host_begin(ctx)) return rc;
-  StreamGuard guard(ctx->host_stream);  // an error return must not leave copies from the caller's memory in flight
+  if (int rc = host_begin(L)) return rc;
+  StreamGuard guard(L->stream);  // an error return must not leave copies from the caller's memory in flight
   // Pieces of up to 256 MiB, chained through init like the callers that feed a file through
   // Extend buffer by buffer (utilities/backupable/backupable_db.cc:1434-1449).
   const size_t piece = (size_t)256 << 20;
-  if (int rc = zc_begin(ctx)) return rc;
+  if (int rc = zc_begin(L)) return rc;
   uint32_t crc = init;
   if (n <= (16u << 10)) {
     // short input: one wave walks it in a single launch, reading it from the zero-copy block (or where it
     // lies, if that is pinned memory) and leaving the result there - no copy commands at all
     const void* base = nullptr;
     if (!is_pinned(h_data, &base)) {
-      memcpy(ctx->zc, h_data, n);
-      base = ctx->zc;
+      memcpy(L->zc, h_data, n);
+      base = L->zc;
     }
     ctx->st_host_bytes_in.fetch_add(n, std::memory_order_relaxed);
     if (int rc = tcrc_dev_blocks_stamp(ctx, base, 1, (uint32_t)n, n, init, -1, nullptr, 0,
-                                       (uint32_t*)(ctx->zc + kZcOutOff), ctx->host_stream))
+                                       (uint32_t*)(L->zc + kZcOutOff), L->stream))
       return rc;
     guard.dismiss();
-    HIP_TRY(hipStreamSynchronize(ctx->host_stream));
-    memcpy(&crc, ctx->zc + kZcOutOff, 4);
+    HIP_TRY(hipStreamSynchronize(L->stream));
+    memcpy(&crc, L->zc + kZcOutOff, 4);
     *out = crc;
     return TCRC_OK;
   }
   for (size_t done = 0; done < n;) {
     const size_t len = n - done < piece ? n - done : piece;
-    if (int rc = upload(ctx, &ctx->host_data, (const uint8_t*)h_data + done, len)) return rc;
+    if (int rc = upload(ctx, L, &L->data, (const uint8_t*)h_data + done, len)) return rc;
     tcrc_desc d;
     d.offset = 0;
     d.len = (uint32_t)len;
     d.init = crc;
     // the result lands in the zero-copy block: the call returns with it complete, no copy back
-    if (int rc = tcrc_dev_extend_long(ctx, ctx->host_data.p, &d, 1, 0, (uint32_t*)(ctx->zc + kZcOutOff),
-                                      ctx->host_stream)) {
-      (void)hipStreamSynchronize(ctx->host_stream);  // the upload may still be reading the caller's memory
+    if (int rc = tcrc_dev_extend_long(ctx, L->data.p, &d, 1, 0, (uint32_t*)(L->zc + kZcOutOff),
+                                      L->stream)) {
+      (void)hipStreamSynchronize(L->stream);  // the upload may still be reading the caller's memory
       return rc;
     }
-    memcpy(&crc, ctx->zc + kZcOutOff, 4);
+    memcpy(&crc, L->zc + kZcOutOff, 4);
     done += len;
   }
   guard.dismiss();  // every piece's call returned with the stream drained

@@ -209,6 +209,16 @@ struct tcrc_scratch {
   size_t bytes = 0;
 };
 
+// What one host-pointer call needs for itself: a stream, staging memory on the device, and a block of pinned,
+// GPU-addressable host memory through which small calls pass descriptors, short inputs and results without
+// copy commands ([data | descriptors | suffix bytes | outputs | expectations | verdicts]).
+struct tcrc_lane {
+  std::mutex mu;  // held for the duration of the call that leased the lane
+  hipStream_t stream = nullptr;
+  tcrc_scratch data, desc, out, aux, blocks, records;
+  char* zc = nullptr;
+};
+
 struct tcrc_ctx {
   int device = -1;
   int cus = 0;
@@ -223,23 +233,25 @@ struct tcrc_ctx {
   void* wal_trace = nullptr;  // development aid: device buffer of 32 x 8 bytes per CU the next scans write timestamps to
   uint64_t wal_calls = 0;  // picks the record-counter slot of a scan (guarded by wal_mu)
   unsigned long long* wal_pin = nullptr;  // 32 words of pinned host memory the scan kernels report record counts into
-  // host-pointer entry points (tcrc_host.hip): their own stream and staging, one call at a time
-  std::mutex host_mu;
-  hipStream_t host_stream = nullptr;
-  tcrc_scratch host_data, host_desc, host_out, host_aux, host_blocks, host_records;
-  // long-buffer scratch (tcrc_long.hip): one call at a time per context.  Lock order: host_mu, then
-  // wal_mu or long_mu.
+  // host-pointer entry points (tcrc_host.hip): every call leases one of the context's lanes, so calls from
+  // different threads (flush and compaction threads share one context) run side by side
+  static constexpr int kMaxLanes = 16;
+  std::mutex lanes_mu;               // guards the vector, not the lanes
+  std::vector<tcrc_lane*> lanes;     // created on demand, freed at shutdown
+  // long-buffer scratch (tcrc_long.hip): one call at a time per context.  Lock order: a lane's mutex, then
+  // wal_mu, long_mu or stage_mu.
   std::mutex long_mu;
   tcrc_scratch long_in, long_acc;
   const uint32_t* d_pow = nullptr;  // kPowTables x kPowEntries words on this GPU (shared by its contexts, never freed)
   uint32_t* d_static = nullptr;     // this GPU's copy of the library's static scratch (accumulator lines first)
   char* long_pin = nullptr;         // pinned staging for the descriptors of a call with more than kLongInline buffers
-  // Small host calls skip the copies: the kernel reads descriptors (and short inputs) from, and writes its
-  // results to, this block of pinned host memory that the GPU addresses directly.  Guarded by host_mu.
+  // Layout constants of a lane's zero-copy block (tcrc_lane::zc)
   static constexpr size_t kZcData = (size_t)64 << 10;     // bounce area for short pageable inputs
   static constexpr size_t kZcMaxItems = 4096;
-  char* zc = nullptr;                                      // [data | descriptors | suffix bytes | outputs]
-  // Staging ring for uploads from pageable memory (tcrc_host.hip), guarded by host_mu
+  // Staging ring for uploads from pageable memory (tcrc_host.hip), shared by the lanes: stage_mu is held while
+  // an upload fills and issues its slots; the slots' events say when a slot's copy (on whichever lane's stream)
+  // has finished
+  std::mutex stage_mu;
   static constexpr int kStageSlots = 12;
   static constexpr size_t kStageSlotBytes = (size_t)4 << 20;
   char* stage_ring = nullptr;  // kStageSlots * kStageSlotBytes of pinned memory

@@ -99,6 +99,7 @@ def test_running_totals():
     assert (st["long_calls"], st["long_bytes"]) == (1, 200000)
     assert (st["log_images"], st["log_bytes"]) == (1, img.size)
     assert st["host_calls"] == 1 and st["host_bytes_in"] == 1000 and st["host_nanos"] > 0
+    assert st["host_lanes"] == 1  # one thread: one lane
     assert capi.lib.tcrc_reset_stats(eng.ctx) == 0
-    assert all(v == 0 for v in eng.stats().values())
+    assert all(v == 0 for k, v in eng.stats().items() if k != "host_lanes")
     eng.close()

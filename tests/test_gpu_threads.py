@@ -59,3 +59,86 @@ def test_entry_points_from_four_threads():
         th.join()
     eng.close()
     assert not errors, errors
+
+
+def _host_mix(eng, t, rounds, check):
+    """The host-pointer calls one flush / compaction / recovery thread makes: a handful of freshly built blocks
+    stamped (WriteRawBlock shape), one fetched block verified (CheckBlockChecksum shape), a 2 MiB extent of
+    blocks verified after a read, and a small log image scanned.  Returns the CRC-covered bytes."""
+    import ctypes as C
+    import terarkdb_amd.capi as capi
+    L = capi.lib
+    rng = np.random.default_rng(100 + t)
+    blen = 4096
+    small = O.splitmix(16 * blen, 300 + t)
+    extent = O.splitmix(512 * blen, 400 + t)
+    img = np.frombuffer(O.build_wal_image(False, n_random=40, seed=9 + t, edge=False), dtype=np.uint8).copy()
+    nb = (img.size + 32767) // 32768
+    want_small = O.sst_trailer_batch(small, blen, blen, 16, 0)
+    want_extent = O.sst_trailer_batch(extent, blen, blen, 512, 0)
+    want_blocks = O.wal_scan_blocks(img.tobytes(), 123)
+
+    def descs(n):
+        d = np.zeros(n, dtype=[("offset", "<u8"), ("len", "<u4"), ("init", "<u4")])
+        d["offset"] = np.arange(n, dtype=np.uint64) * blen
+        d["len"] = blen
+        return d
+
+    d16, d512 = descs(16), descs(512)
+    sfx16, sfx512 = np.zeros(16, np.uint8), np.zeros(512, np.uint8)
+    out16, out512 = np.zeros(16, np.uint32), np.zeros(512, np.uint32)
+    ok512 = np.zeros(512, np.uint8)
+    counts = np.zeros(3, np.uint64)
+    blocks = np.zeros((nb, 4), np.uint32)
+    covered = 0
+    for it in range(rounds):
+        capi.check(L.tcrc_host_batch_stamp(eng.ctx, small.ctypes.data, small.size, d16.ctypes.data, 16,
+                                           sfx16.ctypes.data, capi.F_MASK, out16.ctypes.data))
+        k = int(rng.integers(0, 16))
+        capi.check(L.tcrc_host_batch_verify(eng.ctx, small.ctypes.data + k * blen, blen, d16.ctypes.data, 1,
+                                            sfx16.ctypes.data, 0, want_small[k:k + 1].ctypes.data, out16.ctypes.data,
+                                            None, counts.ctypes.data))
+        bad_verdict = int(counts[0])
+        capi.check(L.tcrc_host_batch_verify(eng.ctx, extent.ctypes.data, extent.size, d512.ctypes.data, 512,
+                                            sfx512.ctypes.data, 0, want_extent.ctypes.data, out512.ctypes.data,
+                                            ok512.ctypes.data, counts.ctypes.data))
+        capi.check(L.tcrc_host_wal_verify(eng.ctx, img.ctypes.data, img.size, 123, blocks.ctypes.data, None, None))
+        covered += 17 * (blen + 1) + 512 * (blen + 1) + img.size
+        if check:
+            assert bad_verdict == 0 and int(counts[0]) == 0 and bool(ok512.all())
+            assert (out512 == want_extent).all() and (blocks == want_blocks).all()
+    return covered
+
+
+def test_eight_threads_share_one_context_through_host_calls():
+    """N flush/compaction threads call WriteRawBlock at once (table/block_based_table_builder.cc:580): on one
+    context their host-pointer calls take separate lanes and run side by side."""
+    import time
+    import gpu_util as G
+    eng = G.engine()
+    _host_mix(eng, 0, 3, True)  # warm: staging, streams
+    t0 = time.perf_counter()
+    one = _host_mix(eng, 0, 40, False)
+    t_one = time.perf_counter() - t0
+    assert eng.stats()["host_lanes"] == 1
+    errors, done = [], []
+
+    def worker(t):
+        try:
+            done.append(_host_mix(eng, t, 40, True))
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    t0 = time.perf_counter()
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    t_eight = time.perf_counter() - t0
+    lanes = eng.stats()["host_lanes"]
+    eng.close()
+    assert not errors, errors
+    assert len(done) == 8 and 2 <= lanes <= 16
+    print(f"\none thread {one / t_one / 1e9:.2f} GB/s, eight threads on one context {sum(done) / t_eight / 1e9:.2f} GB/s "
+          f"({lanes} lanes)")
