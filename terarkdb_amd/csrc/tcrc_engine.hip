@@ -563,27 +563,32 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p, typename 
 // (db/log_reader.cc:314-406).  The image is dealt to the workgroups in chunks of consecutive 32 KiB blocks.
 // Wave 0 of a workgroup walks the record headers - every lane one block, the structural checks of
 // db/log_reader.cc:317-384 - and cuts every checksummed span, from its end, into pieces of at most kWalPiece
-// bytes; one 8-byte entry per piece goes to a list in LDS, densely packed.  All sixteen waves (wave 0 too,
-// once it has filled the next list) take rounds of eight entries from the list and checksum them with eight
-// lanes per entry.  Two lists alternate, so the walk of the next blocks runs beside the checksums of the
-// current ones.
+// bytes; one 8-byte entry per piece goes into a ring in LDS, densely packed, eight entries to a round.  The
+// other fifteen waves (and wave 0 itself, whenever the ring is full and once the walk is over) take rounds
+// from the ring and checksum them with eight lanes per entry.  A round carries a sequence number: the walker
+// may write round t when it reads t, sets it to t + 1 when the round is complete, and whoever took ticket t
+// waits for t + 1, copies the entries out and sets t + ring size - so the walk of the next blocks and the
+// checksums of the current ones run side by side without a barrier.
 // A span of one piece is compared with its stored checksum right away.  The pieces of a longer span (a
 // fragment can be 32 KiB: sixteen pieces, checksummed by different waves at the same time) meet in a slot in
 // LDS: every piece's remainder is multiplied by x^(8 * bytes behind it), XORed into the slot and counted off;
-// whoever counts off last compares the sum with the stored checksum, which the first piece left in the slot.
+// whoever counts off last compares the sum with the stored checksum, which the first piece left in the slot,
+// and frees the slot.
 // Per block the kernel writes (n_records, first_bad, end_offset, end_code); the reference drops the rest of a
 // block at its first bad checksum (db/log_reader.cc:391-397), so that is all its policy code needs.
-constexpr int kWalListRounds = 96;                       // rounds of 8 entries one list holds
-constexpr int kWalListEntries = kWalListRounds * 8;      // 768 entries, 6 KiB
-constexpr uint32_t kWalFirstFillRounds = 24;             // the first list is kept short so that the checksums start early
-constexpr int kWalSlots = 40;                            // spans of several pieces one list can hold
+// Every wait in the kernel is bounded: should the protocol ever stall, the workgroup gives up, and the
+// launch reports 2^62 mismatches instead of hanging the GPU.
+constexpr uint32_t kWalRingRounds = 176;                  // rounds of 8 entries in the ring (11 KiB)
+constexpr int kWalSlots = 63;                             // spans of several pieces in flight (id 63 means "none")
+constexpr uint32_t kWalStepRounds = 64;                   // at most this many rounds are written per walk step
+constexpr uint32_t kWalSpinLimit = 1u << 21;              // bounded waits (about a second)
 // entry: x = block (19 bits) | pieces behind this one << 19 (5 bits) | first piece of its span << 24 | valid << 25 |
 //            slot << 26 (63: the span is this one piece)
 //        y = start inside the block (15 bits) | length << 15
 constexpr uint32_t kWalEntryFirst = 1u << 24, kWalEntryValid = 1u << 25, kWalNoSlot = 63u;
 struct WalSlot {
   uint32_t acc;        // XOR of the pieces' shifted remainders so far
-  uint32_t remaining;  // pieces still to come
+  uint32_t remaining;  // 0: free; else pieces still to come + 1
   uint32_t stored;     // the span's stored checksum, left here by whoever checksums the first piece
   uint32_t blk;        // where the span is: its block and the offset of its first byte in it
   uint32_t start;
@@ -604,20 +609,27 @@ __device__ __forceinline__ uint32_t sum_below_5bit(uint32_t v) {
   return sum;
 }
 
+__device__ __forceinline__ uint32_t lds_load(const uint32_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_store(uint32_t* p, uint32_t v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 template <bool NT>
 __global__ __launch_bounds__(kThreads) void k_wal_fused(WalScanParams p) {
   constexpr int G = 8;
   constexpr int kAuxDwords = AuxDwords<G>::value;
   __shared__ uint32_t lds[kMainDwords + kAuxDwords];
-  __shared__ uint2 list[2][kWalListEntries];
-  __shared__ WalSlot slots[2][kWalSlots];
-  __shared__ uint32_t ctl[2][2];  // per list: [0] rounds in it, [1] next round to hand out
+  __shared__ uint2 ring[kWalRingRounds * 8];
+  __shared__ uint32_t seq[kWalRingRounds];
+  __shared__ WalSlot slots[kWalSlots];
+  // [0] next ticket, [1] rounds in all once the walk is over (till then ~0), [2] set when a wait ran out
+  __shared__ uint32_t ctl[4];
   __shared__ uint32_t pow_piece[16];
 
   const int tid = threadIdx.x;
-  // trace (development aid): wave 0 notes the time at [0] start, [1] first list filled, then per phase
-  // [2 + 3i] its start, [3 + 3i] next list filled, [4 + 3i] wave 0 out of rounds; [31] end
-  uint32_t t_at = 0;
+  // trace (development aid): wave 0 notes the time at [0] start, [1] tables in place, [2] walk over, [31] end
   auto stamp = [&](uint32_t at) {
     if (p.trace && tid == 0 && at < 32u) p.trace[blockIdx.x * 32u + at] = wall_clock64();
   };
@@ -625,10 +637,17 @@ __global__ __launch_bounds__(kThreads) void k_wal_fused(WalScanParams p) {
   for (int i = tid; i < kMainDwords; i += kThreads)
     lds[i] = p.tab_main[((i >> 14) * 2 + ((i >> 5) & 1)) * 256 + ((i >> 6) & 255)];
   for (int i = tid; i < kAuxDwords; i += kThreads) lds[kMainDwords + i] = p.tab_aux[i];
+  for (uint32_t i = tid; i < kWalRingRounds; i += kThreads) seq[i] = i;
+  for (int i = tid; i < kWalSlots; i += kThreads) slots[i].remaining = 0u;
   if (tid == 0) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) pow_piece[i] = p.pow_piece[i];
+    ctl[0] = 0u;
+    ctl[1] = 0xffffffffu;
+    ctl[2] = 0u;
   }
+  __syncthreads();
+  stamp(1);
 
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -651,85 +670,115 @@ __global__ __launch_bounds__(kThreads) void k_wal_fused(WalScanParams p) {
   };
 
   // walker state (wave 0): every lane walks one block at a time
-  uint32_t w_next = 0;  // next number to hand to an idle lane (the same in every lane)
+  uint32_t w_next = 0;   // next number to hand to an idle lane (the same in every lane)
   uint32_t w_blk = 0, w_pos = 0, w_k = 0, w_records = 0;
   bool w_active = false;
+  uint32_t w_count = 0;  // entries written to the ring so far (the same in every lane)
+  uint32_t w_open = 0;   // rounds [0, w_open) are known to be the walker's to write or already written
+  uint32_t w_spans = 0;  // spans of several pieces so far: span n uses slot n mod kWalSlots
+  bool w_done = false;   // the walk is over and the last round is out
 
-  // Fills list L with up to cap_rounds rounds; leaves its round count in ctl[L].
-  auto fill = [&](int L, uint32_t cap_rounds) {
-    const uint32_t cap = cap_rounds * 8u;
-    uint32_t count = 0, used = 0;  // entries in the list, slots taken
-    for (;;) {
-      const unsigned long long idle = __ballot(!w_active);
-      if (idle && w_next < b_hi) {
-        const uint32_t nv = w_next + lanes_below(idle);
-        const uint32_t nb = block_of(nv);
-        if (!w_active && nv < b_hi && nb < p.nblocks) {
-          w_active = true;
-          w_blk = nb;
-          w_pos = 0;
-          w_k = 0;
-          p.blocks[nb].first_bad = 0xffffffffu;  // lowered by whoever finds a bad checksum in the block
-        }
-        const uint32_t handed = w_next + (uint32_t)__popcll(idle);
-        w_next = handed < b_hi ? handed : b_hi;
+  // One step of the walk: every active lane looks at the record under its cursor and, if there is room, puts
+  // the record's pieces into the ring.  Returns true if the ring (or the slots) had no room for some record.
+  auto walk_step = [&]() -> bool {
+    const unsigned long long idle = __ballot(!w_active);
+    if (idle && w_next < b_hi) {
+      const uint32_t nv = w_next + lanes_below(idle);
+      const uint32_t nb = block_of(nv);
+      if (!w_active && nv < b_hi && nb < p.nblocks) {
+        w_active = true;
+        w_blk = nb;
+        w_pos = 0;
+        w_k = 0;
+        p.blocks[nb].first_bad = 0xffffffffu;  // lowered by whoever finds a bad checksum in the block
       }
-      if (!__any(w_active)) break;  // nothing left to walk
-      const uint64_t base = (uint64_t)w_blk * kLogBlockBytes;
-      const uint64_t end = base + kLogBlockBytes < p.size ? base + kLogBlockBytes : p.size;
-      const bool last = p.tail && end == p.size;
-      uint32_t hs = 0, len = 0, code = 0;
-      bool ok = false;
-      if (w_active) ok = wal_step(p.img, base + w_pos, end, last, p.log_number, &hs, &len, &code);
-      if (w_active && !ok) {  // the block's walk ends here: that needs no room in the list
-        tcrc_wal_block* b = p.blocks + w_blk;
-        b->n_records = w_k;
-        b->end_offset = w_pos;
-        b->end_code = code;
-        w_records += w_k;
-        w_active = false;
-      }
-      // the CRC covers the type byte, the log number if any, and the payload
-      const uint32_t span = len + hs - 6u;
-      const uint32_t c = ok ? (span + kWalPiece - 1u) / kWalPiece : 0u;  // 1..16 pieces
-      const bool multi = c > 1u;
-      // Lanes take room in lane order; those that no longer fit (a list takes 96 rounds and 40 spans of several
-      // pieces) keep their record for the next list.  The lowest lane with a record always fits an empty list.
-      const uint32_t upto_e = sum_below_5bit(c) + c, upto_s = lanes_below(__ballot(multi)) + (multi ? 1u : 0u);
-      const bool fits = ok && count + upto_e <= cap && used + upto_s <= (uint32_t)kWalSlots;
-      if (fits) {
-        const uint32_t slot = multi ? used + upto_s - 1u : kWalNoSlot;
-        const uint32_t start = w_pos + 6u, stop = start + span;
-        uint2* e = &list[L][count + upto_e - c];
-        for (uint32_t i = 0; i < c; ++i) {
-          const uint32_t q = c - 1u - i;  // pieces behind piece i
-          const uint32_t pe = stop - q * kWalPiece;
-          const uint32_t ps = i == 0u ? start : pe - kWalPiece;
-          e[i] = make_uint2(w_blk | (q << 19) | (i == 0u ? kWalEntryFirst : 0u) | kWalEntryValid | (slot << 26),
-                            ps | ((pe - ps) << 15));
-        }
-        if (multi) {
-          slots[L][slot].acc = 0u;
-          slots[L][slot].remaining = c;
-        }
-        w_pos += hs + len;
-        ++w_k;
-      }
-      const unsigned long long m_fit = __ballot(fits);
-      if (m_fit) {
-        const int top = 63 - __builtin_clzll(m_fit);
-        count += (uint32_t)__shfl((int)upto_e, top);
-        used += (uint32_t)__shfl((int)upto_s, top);
-      }
-      if (__any(ok && !fits)) break;  // full
+      const uint32_t handed = w_next + (uint32_t)__popcll(idle);
+      w_next = handed < b_hi ? handed : b_hi;
     }
-    // the last round is padded with empty entries
-    const uint32_t pad = (8u - (count & 7u)) & 7u;
-    if ((uint32_t)lane < pad) list[L][count + lane] = make_uint2(0u, 0u);
-    if (lane == 0) {
-      ctl[L][0] = (count + 7u) >> 3;
-      ctl[L][1] = 0u;
+    if (!__any(w_active)) {
+      // Nothing left to walk: the last round is padded with empty entries and goes out, and the number of
+      // rounds is made known.  (The round is the walker's: w_open covers it, see below.)
+      const uint32_t pad = (8u - (w_count & 7u)) & 7u;
+      if (pad) {
+        if ((uint32_t)lane < pad) ring[(w_count + lane) % (kWalRingRounds * 8u)] = make_uint2(0u, 0u);
+        if (lane == 0) __hip_atomic_store(&seq[(w_count >> 3) % kWalRingRounds], (w_count >> 3) + 1u, __ATOMIC_RELEASE,
+                                          __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      if (lane == 0) lds_store(&ctl[1], (w_count + 7u) >> 3);
+      w_done = true;
+      return false;
     }
+    const uint64_t base = (uint64_t)w_blk * kLogBlockBytes;
+    const uint64_t end = base + kLogBlockBytes < p.size ? base + kLogBlockBytes : p.size;
+    const bool last = p.tail && end == p.size;
+    uint32_t hs = 0, len = 0, code = 0;
+    bool ok = false;
+    if (w_active) ok = wal_step(p.img, base + w_pos, end, last, p.log_number, &hs, &len, &code);
+    if (w_active && !ok) {  // the block's walk ends here: that needs no room in the ring
+      tcrc_wal_block* b = p.blocks + w_blk;
+      b->n_records = w_k;
+      b->end_offset = w_pos;
+      b->end_code = code;
+      w_records += w_k;
+      w_active = false;
+    }
+    // the CRC covers the type byte, the log number if any, and the payload
+    const uint32_t span = len + hs - 6u;
+    const uint32_t c = ok ? (span + kWalPiece - 1u) / kWalPiece : 0u;  // 1..16 pieces
+    const bool multi = c > 1u;
+    // Room: rounds from the one w_count points into onwards are the walker's once their sequence number says
+    // so.  Only when what is known to be free does not take this step's entries are the sequence numbers looked
+    // at again: lane i looks at round w_open + i; the rounds up to the first one that is still somebody's are
+    // added.
+    uint32_t step_entries = 0;
+#pragma unroll
+    for (int b = 0; b < 5; ++b) step_entries += (uint32_t)__popcll(__ballot((c >> b) & 1u)) << b;
+    if (step_entries > w_open * 8u - w_count) {
+      const uint32_t t = w_open + (uint32_t)lane;
+      const bool mine = (uint32_t)lane < kWalStepRounds && lds_load(&seq[t % kWalRingRounds]) == t;
+      const unsigned long long m = __ballot(mine);
+      w_open += m == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~m);
+      if (w_open > (w_count >> 3) + kWalStepRounds) w_open = (w_count >> 3) + kWalStepRounds;
+    }
+    const uint32_t room = w_open * 8u - w_count;
+    // Lanes take room in lane order; those that no longer fit keep their record for the next step.  A span of
+    // several pieces also needs its slot to be free.
+    const uint32_t upto_e = sum_below_5bit(c) + c;
+    const uint32_t my_span = w_spans + lanes_below(__ballot(multi));
+    const bool slot_busy = multi && lds_load(&slots[my_span % kWalSlots].remaining) != 0u;
+    const unsigned long long m_busy = __ballot(slot_busy || (multi && my_span - w_spans >= (uint32_t)kWalSlots));
+    const bool before_busy = m_busy == 0ull || lane < __builtin_ctzll(m_busy);
+    const bool fits = ok && upto_e <= room && before_busy;
+    if (fits) {
+      const uint32_t slot = multi ? my_span % kWalSlots : kWalNoSlot;
+      const uint32_t start = w_pos + 6u, stop = start + span;
+      const uint32_t at = w_count + upto_e - c;
+      for (uint32_t i = 0; i < c; ++i) {
+        const uint32_t q = c - 1u - i;  // pieces behind piece i
+        const uint32_t pe = stop - q * kWalPiece;
+        const uint32_t ps = i == 0u ? start : pe - kWalPiece;
+        ring[(at + i) % (kWalRingRounds * 8u)] =
+            make_uint2(w_blk | (q << 19) | (i == 0u ? kWalEntryFirst : 0u) | kWalEntryValid | (slot << 26), ps | ((pe - ps) << 15));
+      }
+      if (multi) {
+        slots[slot].acc = 0u;
+        lds_store(&slots[slot].remaining, c + 1u);
+      }
+      w_pos += hs + len;
+      ++w_k;
+    }
+    const unsigned long long m_fit = __ballot(fits);
+    if (m_fit) {
+      const int top = 63 - __builtin_clzll(m_fit);
+      const uint32_t new_count = w_count + (uint32_t)__shfl((int)upto_e, top);
+      w_spans += (uint32_t)__popcll(__ballot(fits && multi));
+      // rounds that are complete now go out: lane i publishes round (old count / 8) + i
+      const uint32_t r0 = w_count >> 3, r1 = new_count >> 3;
+      if ((uint32_t)lane < r1 - r0)
+        __hip_atomic_store(&seq[(r0 + lane) % kWalRingRounds], r0 + lane + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      w_count = new_count;
+    }
+    return __any(ok && !fits);
   };
 
   // A checksum that does not match: counted, and the record's index inside its block - found by walking the
@@ -748,59 +797,100 @@ __global__ __launch_bounds__(kThreads) void k_wal_fused(WalScanParams p) {
     atomicMin(&p.blocks[blk].first_bad, k);
   };
 
-  if (wave == 0) fill(0, p.first_rounds);
-  stamp(1);
-  __syncthreads();
-  for (int L = 0;; L ^= 1) {
-    const uint32_t nrounds = ctl[L][0];
-    if (nrounds == 0u) break;  // nothing was left to walk
-    stamp(2u + 3u * t_at);
-    if (wave == 0) fill(L ^ 1, p.list_rounds);
-    stamp(3u + 3u * t_at);
-    for (;;) {
-      uint32_t r = 0;
-      if (lane == 0) r = atomicAdd(&ctl[L][1], 1u);
-      r = (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
-      if (r >= nrounds) break;
-      const uint2 e = list[L][r * 8u + grp];
-      const bool valid = (e.x & kWalEntryValid) != 0u;
-      const bool first = (e.x & kWalEntryFirst) != 0u;
-      const uint32_t blk = e.x & 0x7ffffu, q = (e.x >> 19) & 31u, slot = e.x >> 26;
-      const uint32_t start = e.y & 0x7fffu, len = e.y >> 15;
-      const uint8_t* ptr = p.img + (uint64_t)blk * kLogBlockBytes + start;
-      // the stored value is fetched now so its latency hides behind the row loop
-      uint32_t stored = 0;
-      if (valid && first && j == G - 1) __builtin_memcpy(&stored, ptr - 6, 4);
-      const uint32_t core = span_remainder<G, NT>(lds, LB, lane, ptr, len, first ? 0u : 0xffffffffu, valid, false,
-                                                  (const uint8_t*)p.tab_main);
-      if (valid && j == G - 1) {
-        if (slot == kWalNoSlot) {
-          const uint32_t crc = ~core;
-          if (stored != ((crc >> 15) | (crc << 17)) + kMaskDelta) mismatch(blk, start);
-        } else {
-          WalSlot* sl = &slots[L][slot];
-          if (first) {
-            __hip_atomic_store(&sl->stored, stored, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_store(&sl->blk, blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_store(&sl->start, start, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          }
-          const uint32_t v = q ? gf2_mulmod_dev(core, pow_piece[q]) : core;
-          (void)__hip_atomic_fetch_xor(&sl->acc, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          // release what this piece left in the slot, acquire what the others left
-          const uint32_t before = __hip_atomic_fetch_sub(&sl->remaining, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-          if (before == 1u) {
-            const uint32_t crc = ~__hip_atomic_load(&sl->acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const uint32_t want = __hip_atomic_load(&sl->stored, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (want != ((crc >> 15) | (crc << 17)) + kMaskDelta)
-              mismatch(__hip_atomic_load(&sl->blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP),
-                       __hip_atomic_load(&sl->start, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-          }
+  uint32_t spins = 0;
+  for (;;) {
+    if (lds_load(&ctl[2])) break;  // some wave of the workgroup gave up waiting
+    uint32_t t = 0;
+    if (wave == 0 && !w_done) {
+      __builtin_amdgcn_s_setprio(3);  // the walk is the critical path of a workgroup with little to do
+      // The walker.  While its records find room it only walks; when they do not, it takes a round itself if one
+      // is out that nobody has taken (so that it never waits for a round only it could write).
+      if (!walk_step()) {
+        if (w_done) {
+          stamp(2);
+          __builtin_amdgcn_s_setprio(0);
+        }
+        continue;
+      }
+      __builtin_amdgcn_s_setprio(0);  // about to checksum a round (or to wait): like everybody else
+      uint32_t got = 0xffffffffu;
+      if (lane == 0) {
+        const uint32_t out = w_count >> 3;  // rounds that are out
+        uint32_t h = lds_load(&ctl[0]);
+        while (h < out && !__hip_atomic_compare_exchange_strong(&ctl[0], &h, h + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                                  __HIP_MEMORY_SCOPE_WORKGROUP)) {
+        }
+        if (h < out) got = h;
+      }
+      got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
+      if (got == 0xffffffffu) {  // all rounds that are out are being worked on: their slots come back soon
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > kWalSpinLimit) lds_store(&ctl[2], 1u);
+        continue;
+      }
+      t = got;
+    } else {
+      if (lane == 0) t = atomicAdd(&ctl[0], 1u);
+      t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+      bool over = false;
+      for (;;) {
+        const uint32_t s = (uint32_t)__builtin_amdgcn_readfirstlane(
+            (int)__hip_atomic_load(&seq[t % kWalRingRounds], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if (s == t + 1u) break;
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_load(&ctl[1]));
+        if (t >= total || lds_load(&ctl[2])) {
+          over = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > kWalSpinLimit) {
+          lds_store(&ctl[2], 1u);
+          over = true;
+          break;
+        }
+      }
+      if (over) break;
+    }
+    spins = 0;
+    // round t: the entries are copied out, and the round is handed back to the walker
+    const uint2 e = ring[(t % kWalRingRounds) * 8u + grp];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every lane has its entry before the round is given away
+    if (lane == 0)
+      __hip_atomic_store(&seq[t % kWalRingRounds], t + kWalRingRounds, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const bool valid = (e.x & kWalEntryValid) != 0u;
+    const bool first = (e.x & kWalEntryFirst) != 0u;
+    const uint32_t blk = e.x & 0x7ffffu, q = (e.x >> 19) & 31u, slot = e.x >> 26;
+    const uint32_t start = e.y & 0x7fffu, len = e.y >> 15;
+    const uint8_t* ptr = p.img + (uint64_t)blk * kLogBlockBytes + start;
+    // the stored value is fetched now so its latency hides behind the row loop
+    uint32_t stored = 0;
+    if (valid && first && j == G - 1) __builtin_memcpy(&stored, ptr - 6, 4);
+    const uint32_t core = span_remainder<G, NT>(lds, LB, lane, ptr, len, first ? 0u : 0xffffffffu, valid, false,
+                                                (const uint8_t*)p.tab_main);
+    if (valid && j == G - 1) {
+      if (slot == kWalNoSlot) {
+        const uint32_t crc = ~core;
+        if (stored != ((crc >> 15) | (crc << 17)) + kMaskDelta) mismatch(blk, start);
+      } else {
+        WalSlot* sl = &slots[slot];
+        if (first) {
+          lds_store(&sl->stored, stored);
+          lds_store(&sl->blk, blk);
+          lds_store(&sl->start, start);
+        }
+        const uint32_t v = q ? gf2_mulmod_dev(core, pow_piece[q]) : core;
+        (void)__hip_atomic_fetch_xor(&sl->acc, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // release what this piece left in the slot, acquire what the others left
+        const uint32_t before = __hip_atomic_fetch_sub(&sl->remaining, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (before == 2u) {  // the last piece: compare, then give the slot back
+          const uint32_t crc = ~lds_load(&sl->acc);
+          const uint32_t want = lds_load(&sl->stored);
+          const uint32_t sblk = lds_load(&sl->blk), sstart = lds_load(&sl->start);
+          __hip_atomic_store(&sl->remaining, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (want != ((crc >> 15) | (crc << 17)) + kMaskDelta) mismatch(sblk, sstart);
         }
       }
     }
-    stamp(4u + 3u * t_at);
-    ++t_at;
-    __syncthreads();
   }
   stamp(31);
   if (wave == 0) {
@@ -809,6 +899,7 @@ __global__ __launch_bounds__(kThreads) void k_wal_fused(WalScanParams p) {
     for (int o = 32; o >= 1; o >>= 1) total += __shfl_xor(total, o);
     if (lane == 0) {
       if (total) atomicAdd(&p.counts[TCRC_CNT_CHECKED], (unsigned long long)total);
+      if (lds_load(&ctl[2])) atomicAdd(&p.counts[TCRC_CNT_MISMATCH], 1ull << 62);  // a wait ran out: say so loudly
       if (p.records_host) {
         // The launch's record count goes to the host without a copy command: workgroups add theirs to a device
         // word and count themselves off; the last one takes the sum out (leaving both words zero for the next
@@ -976,15 +1067,6 @@ int run_wal_scan(tcrc_ctx* ctx, WalScanParams p, void* stream) {
   p.tab_main = ctx->d_tab_main[gi];
   p.tab_aux = ctx->d_tab_aux[gi];
   for (uint32_t q = 0; q < 16; ++q) p.pow_piece[q] = tcrc::gf2_xpow(8ull * kWalPiece * q);
-  p.first_rounds = kWalFirstFillRounds;
-  // A workgroup with little to walk (a few dozen blocks) is done walking long before it is done checksumming:
-  // shorter lists then mean shorter phases and a shorter wait for what the walker found last (measured on a
-  // 256 MiB log: 82-87 us with 96 rounds, 81-83 us with 48; a 2 GB log: 359 us with 96, 375 us with 48).
-  p.list_rounds = p.nblocks / (uint32_t)ctx->cus < 64u ? kWalListRounds / 2 : kWalListRounds;
-  if (const char* e = getenv("TCRC_WAL_LIST_ROUNDS")) {  // experiments only
-    const int v = atoi(e);
-    if (v >= 8 && v <= kWalListRounds) p.list_rounds = (uint32_t)v;
-  }
   p.trace = (unsigned long long*)ctx->wal_trace;
   // chunks of up to 64 blocks (one per walker lane), at least two chunks per workgroup
   p.chunk_shift = 6;
@@ -992,10 +1074,6 @@ int run_wal_scan(tcrc_ctx* ctx, WalScanParams p, void* stream) {
   if (const char* e = getenv("TCRC_WAL_CHUNK_SHIFT")) {  // experiments only
     const int v = atoi(e);
     if (v >= 0 && v <= 20) p.chunk_shift = (uint32_t)v;
-  }
-  if (const char* e = getenv("TCRC_WAL_FIRST_ROUNDS")) {  // experiments only
-    const int v = atoi(e);
-    if (v >= 1 && v <= kWalListRounds) p.first_rounds = (uint32_t)v;
   }
   const unsigned wgs = p.nblocks < (uint32_t)ctx->cus ? p.nblocks : (unsigned)ctx->cus;
   hipStream_t s = (hipStream_t)stream;

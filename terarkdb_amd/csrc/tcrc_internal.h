@@ -55,17 +55,23 @@ __device__ __forceinline__ bool wal_step(const uint8_t* img, uint64_t pos, uint6
     *code = remaining == 0 ? TCRC_WAL_END_CLEAN : (last ? TCRC_WAL_END_SHORT_AT_EOF : TCRC_WAL_END_TRAILER);
     return false;
   }
+  // The log number of a recyclable header is fetched together with length and type (when the bytes are there
+  // at all), not after the type has come back: the walk is a chain of dependent loads, and this halves the
+  // chain for recyclable logs.
   const uint8_t* h = img + pos;
-  const uint32_t len = (uint32_t)h[4] | ((uint32_t)h[5] << 8);
+  const bool has11 = remaining >= kLogRecyclableHeader;
+  const uint32_t b4 = h[4], b5 = h[5];
   const uint32_t type = (uint32_t)(int)(signed char)h[6];  // the reference reads it through a char
+  uint32_t lognum = 0;
+  if (has11) lognum = (uint32_t)h[7] | ((uint32_t)h[8] << 8) | ((uint32_t)h[9] << 16) | ((uint32_t)h[10] << 24);
+  const uint32_t len = b4 | (b5 << 8);
   uint32_t hs = kLogHeader;
   if (type >= 5u && type <= 8u) {
     hs = kLogRecyclableHeader;
-    if (remaining < kLogRecyclableHeader) {
+    if (!has11) {
       *code = last ? TCRC_WAL_END_SHORT_AT_EOF : TCRC_WAL_END_TRAILER;
       return false;
     }
-    const uint32_t lognum = (uint32_t)h[7] | ((uint32_t)h[8] << 8) | ((uint32_t)h[9] << 16) | ((uint32_t)h[10] << 24);
     if ((uint64_t)lognum != log_number) {
       *code = TCRC_WAL_END_OLD_RECORD;
       return false;
@@ -120,8 +126,6 @@ struct WalScanParams {
   uint32_t nblocks;
   uint32_t tail;               // the slice ends where the file ends
   uint32_t chunk_shift;        // log2 of the blocks per chunk dealt to a workgroup at a time
-  uint32_t list_rounds;        // rounds the later lists are cut off at (at most what a list holds)
-  uint32_t first_rounds;       // rounds the first list is cut off at (the checksums start once it is filled)
   tcrc_wal_block* blocks;      // [nblocks]
   unsigned long long* counts;  // the caller's TCRC_CNT_* block (accumulated into)
   unsigned long long* records_host;  // when not NULL: the launch's candidate records are added to this word of

@@ -36,10 +36,10 @@ capi.lib.tcrc_debug_wal_trace(eng.ctx, None)
 t = trace.cpu().numpy().reshape(256, 32).astype(np.float64)
 t0 = t[:, 0].min()
 us = np.where(t > 0, (t - t0) / 100.0, np.nan)
-names = ["start", "list0 filled"] + sum([[f"ph{i} start", f"ph{i} next filled", f"ph{i} wave0 done"] for i in range(9)], []) + ["-", "-", "end"]
+names = {0: "start", 1: "tables in place", 2: "walk over", 31: "end"}
 print("event: min / median / max over workgroups (us since first start)")
 for k in range(32):
     col = us[:, k]
     if np.isnan(col).all():
         continue
-    print(f"{names[k]:18s} {np.nanmin(col):7.1f} {np.nanmedian(col):7.1f} {np.nanmax(col):7.1f}   ({int((~np.isnan(col)).sum())} wgs)")
+    print(f"{names.get(k, str(k)):18s} {np.nanmin(col):7.1f} {np.nanmedian(col):7.1f} {np.nanmax(col):7.1f}   ({int((~np.isnan(col)).sum())} wgs)")
