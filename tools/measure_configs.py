@@ -130,8 +130,10 @@ def run_blocks_var(eng, name, target):
     del img_h
     alg = int(lens.sum()) + nblk
     what = f"1 GiB of {target}..{target + 256}-byte blocks packed with their 5-byte trailers ({nblk} blocks, descriptor list)"
-    line(name + "_verify", what + ": verify against the trailers in the image", "k_crc_batch<8>", alg, sustained(verify))
-    line(name + "_stamp", what + ": stamp the trailers into the image", "k_crc_batch<8>", alg, sustained(stamp))
+    if ARGS.phase in ("", "verify"):
+        line(name + "_verify", what + ": verify against the trailers in the image", "k_crc_batch<8>", alg, sustained(verify))
+    if ARGS.phase in ("", "stamp"):
+        line(name + "_stamp", what + ": stamp the trailers into the image", "k_crc_batch<8>", alg, sustained(stamp))
 
 
 def run_spans(eng):
@@ -189,6 +191,7 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--launches", type=int, default=50)
     ap.add_argument("--settle", type=float, default=2.0)
+    ap.add_argument("--phase", default="", help="blocks*_var only: verify or stamp (both when empty)")
     ARGS = ap.parse_args()
     only = set(x for x in ARGS.only.split(",") if x)
     eng = capi.Engine(0)
