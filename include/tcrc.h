@@ -171,10 +171,10 @@ typedef struct tcrc_wal_block {
  * d_blocks[b] describes block b = bytes [32768*b, 32768*(b+1)) of the image.  Within a
  * block the reference stops at the first bad checksum, so first_bad is what its policy
  * layer needs.  d_counts accumulates TCRC_CNT_* over all candidate records (TCRC_CNT_FIRST_BAD
- * is the index of the first 32 KiB block that holds a mismatching record).  Synchronises
- * the stream once per 8 GiB (the record count is needed on the host); on return the rest
- * of the work is enqueued on `stream`.  *h_records, if not NULL, receives the number of
- * candidate records. */
+ * is the index of the first 32 KiB block that holds a mismatching record).  One kernel
+ * launch per 16 GiB of image.  With h_records NULL the call only enqueues on `stream`;
+ * otherwise it waits for the stream and *h_records receives the number of candidate
+ * records (the kernel hands it over through pinned host memory, no copy command). */
 int tcrc_dev_wal_verify(tcrc_ctx* ctx, const void* d_img, uint64_t size, uint64_t log_number, tcrc_wal_block* d_blocks,
                         uint64_t* d_counts, uint64_t* h_records, void* stream);
 
