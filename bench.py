@@ -105,8 +105,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # Rehearsal of the N > 1 path on a box with ONE GPU: the ranks share cuda:0 and meet over gloo (RCCL refuses
+    # two ranks on one device).  The sharding, the fixture checks and the collective's arithmetic are the real
+    # ones; the rate is not a scaling result and the line says so.
+    rehearsal = os.environ.get("TCRC_BENCH_REHEARSAL") == "1"
     dist = None
-    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:
+    if rehearsal:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        local_rank = 0
+    elif world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:
         # under torchrun the process group is used even with one rank, so the same code path runs at every N
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -181,7 +190,8 @@ def main():
     # and the launches after that run up to 10 % slower for the next hundred launches.
     shard_lo = lambda r: shard_range(TOTAL_BLOCKS, r, world)[0]  # noqa: E731
     step()
-    gather_verify_counts(counts, shard_lo)
+    on_wire = (lambda c: c.cpu()) if rehearsal else (lambda c: c)  # gloo carries host tensors
+    gather_verify_counts(on_wire(counts), shard_lo)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     e1.record()
@@ -225,7 +235,7 @@ def main():
     t_enq = time.perf_counter()
     # the path's only exchange: every rank's {mismatches, first bad block, checked}, one all-gather (RCCL)
     # of the engine's device counter block; the copy to the host waits for the K launches
-    totals = gather_verify_counts(counts, shard_lo)
+    totals = gather_verify_counts(on_wire(counts), shard_lo)
     t_cnt = time.perf_counter()
     # That all-gather is the closing barrier: no rank gets its result before every rank has contributed its
     # counters, which a rank's stream produces only after its K launches.  A second collective would only add
@@ -236,7 +246,7 @@ def main():
         print(f"[rank {rank}] enqueue {1e6*(t_enq-t0):.0f} us, counters back {1e6*(t_cnt-t0):.0f} us, "
               f"end {1e6*elapsed:.0f} us", file=sys.stderr)
     if dist:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
@@ -274,6 +284,8 @@ def main():
                        "sharding": "contiguous block range per GPU", "gib_folds_checked_on_rank0": gibs_checked,
                        "seeded_corruptions": n_corrupt,
                        "collective": "one all-gather of {mismatches, checked, first_bad} (24 B per rank)" if dist else "none"},
+            **({"rehearsal": f"{world} ranks sharing ONE GPU over gloo: a check of the sharded path, not a scaling result"}
+               if rehearsal else {}),
             "pct_hbm_peak": round(100.0 * value / (HBM_PEAK_GBS * world), 2),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

@@ -357,14 +357,28 @@ template <> struct SegArgs<true> { typedef LongArgs type; };
 // protocol needs is that a wave's XOR has been performed before its count is added, i.e. that the XOR's
 // acknowledgement has come back: a wait on the vector-memory counter.
 __device__ __forceinline__ void seg_arrive(uint32_t* line, uint32_t value, uint32_t count, uint32_t total,
-                                           uint32_t* out) {
+                                           uint32_t* out, const DoneSignal& done, uint32_t nbuf) {
   (void)__hip_atomic_fetch_xor(line, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const uint32_t before = __hip_atomic_fetch_add(line + 1, count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (before + count == total) {  // every other segment's XOR was acknowledged before its count was added
     const uint32_t r = __hip_atomic_exchange(line, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     (void)__hip_atomic_exchange(line + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    *out = r;
+    if (!done.flag) {
+      *out = r;
+    } else {
+      // a host thread is watching for the flag: the result is written through to memory and counted off
+      // behind a system-scope release (a store is acknowledged to its wave by the L2, which may still hold
+      // it; and the flag takes another channel of the L2)
+      __hip_atomic_store(out, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+      bool last = nbuf == 1u;
+      if (!last) {
+        last = __hip_atomic_fetch_add(done.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == nbuf;
+        if (last) (void)__hip_atomic_exchange(done.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (last) __hip_atomic_store(done.flag, done.value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 
@@ -549,13 +563,31 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p, typename 
         for (int o = 32; o >= 1; o >>= 1) v ^= __shfl_xor(v, o);
         if (lane == 0 && have)
           seg_arrive(la.acc + (uint64_t)first_owner * 32u, v, (uint32_t)__popcll(have), first_total,
-                     p.out + first_owner);
+                     p.out + first_owner, p.done, la.nbuf);
       } else if (seg_have) {
-        seg_arrive(la.acc + (uint64_t)seg_owner * 32u, seg_value, 1u, seg_total, p.out + seg_owner);
+        seg_arrive(la.acc + (uint64_t)seg_owner * 32u, seg_value, 1u, seg_total, p.out + seg_owner, p.done, la.nbuf);
       }
     }
   }
   if (p.verify && blockIdx.x == 0 && tid == 0) atomicAdd(&p.counts[TCRC_CNT_CHECKED], (unsigned long long)n);
+  if constexpr (!SEG) {
+    if (p.done.flag) {
+      // Every wave's stores have been acknowledged by the L2 at the barrier; a system-scope release by one
+      // thread then pushes them out of this XCD's L2 (it may still hold them, and the flag takes another of
+      // its channels).  The workgroups count themselves off; the last one tells the host.
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        bool last = gridDim.x == 1u;
+        if (!last) {
+          last = __hip_atomic_fetch_add(p.done.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == gridDim.x;
+          if (last) (void)__hip_atomic_exchange(p.done.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (last) __hip_atomic_store(p.done.flag, p.done.value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
 }
 
 // ---- log scan --------------------------------------------------------------------------------------------
@@ -1144,6 +1176,7 @@ int tcrc_init(int device, tcrc_ctx** out) {
   ctx->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (const char* e = getenv("TCRC_LANES_PER_BUFFER")) ctx->forced_g = atoi(e);
   if (const char* e = getenv("TCRC_NONTEMPORAL")) ctx->nontemporal = atoi(e) != 0;
+  if (const char* e = getenv("TCRC_NO_POLL")) ctx->poll_completion = atoi(e) == 0;
   for (int gi = 0; gi < kGeoCount; ++gi) {
     const int G = kGeoLanes[gi];
     int log2g = 0;
@@ -1200,12 +1233,14 @@ int tcrc_shutdown(tcrc_ctx* ctx) {
     for (tcrc_scratch* s : {&l->data, &l->desc, &l->out, &l->aux, &l->blocks, &l->records}) scratch_release(s);
     if (l->stream) (void)hipStreamDestroy(l->stream);
     if (l->zc) (void)hipHostFree(l->zc);
+    if (l->done_counter) (void)hipFree(l->done_counter);
     delete l;
   }
   ctx->lanes.clear();
   for (auto& e : ctx->pin_free) (void)hipHostFree(e.first);
   if (ctx->stage_ring) (void)hipHostFree(ctx->stage_ring);
   if (ctx->long_pin) (void)hipHostFree(ctx->long_pin);
+  if (ctx->long_flag) (void)hipHostFree(ctx->long_flag);
   if (ctx->wal_pin) (void)hipHostFree(ctx->wal_pin);
   for (hipEvent_t ev : ctx->stage_done)
     if (ev) (void)hipEventDestroy(ev);
@@ -1327,6 +1362,22 @@ int tcrc_dev_blocks_verify(tcrc_ctx* ctx, const void* d_base, uint64_t n_blocks,
 
 int tcrc_dev_batch_stamp(tcrc_ctx* ctx, const void* d_base, const tcrc_desc* d_desc, uint64_t n,
                          const uint8_t* d_suffix, uint32_t flags, uint32_t* d_out, void* stream) {
+  return tcrc_internal::batch_stamp(ctx, d_base, d_desc, n, d_suffix, flags, d_out, stream, DoneSignal{});
+}
+
+int tcrc_dev_batch_verify(tcrc_ctx* ctx, const void* d_base, const tcrc_desc* d_desc, uint64_t n,
+                          const uint8_t* d_suffix, uint32_t flags, const uint32_t* d_expected, uint32_t* d_out,
+                          uint8_t* d_ok, uint64_t* d_counts, void* stream) {
+  return tcrc_internal::batch_verify(ctx, d_base, d_desc, n, d_suffix, flags, d_expected, d_out, d_ok, d_counts, stream,
+                                     DoneSignal{});
+}
+
+}  // extern "C"
+
+namespace tcrc_internal {
+
+int batch_stamp(tcrc_ctx* ctx, const void* d_base, const tcrc_desc* d_desc, uint64_t n, const uint8_t* d_suffix,
+                uint32_t flags, uint32_t* d_out, void* stream, const DoneSignal& done) {
   if (int rc = check_flags(flags, kStampFlags)) return rc;
   if (n && (!d_desc || (!d_out && !(flags & TCRC_F_STORE_AFTER))))
     return fail(TCRC_ERR_INVALID, "null descriptor or output pointer");
@@ -1338,12 +1389,13 @@ int tcrc_dev_batch_stamp(tcrc_ctx* ctx, const void* d_base, const tcrc_desc* d_d
   p.uniform_suffix = -1;
   p.flags = flags;
   p.out = d_out;
+  p.done = done;
   return run_batch(ctx, p, stream);
 }
 
-int tcrc_dev_batch_verify(tcrc_ctx* ctx, const void* d_base, const tcrc_desc* d_desc, uint64_t n,
-                          const uint8_t* d_suffix, uint32_t flags, const uint32_t* d_expected, uint32_t* d_out,
-                          uint8_t* d_ok, uint64_t* d_counts, void* stream) {
+int batch_verify(tcrc_ctx* ctx, const void* d_base, const tcrc_desc* d_desc, uint64_t n, const uint8_t* d_suffix,
+                 uint32_t flags, const uint32_t* d_expected, uint32_t* d_out, uint8_t* d_ok, uint64_t* d_counts,
+                 void* stream, const DoneSignal& done) {
   if (n && !d_desc) return fail(TCRC_ERR_INVALID, "null descriptor pointer");
   if (int rc = check_flags(flags, kVerifyFlags)) return rc;
   if (!d_counts) return fail(TCRC_ERR_INVALID, "verify needs a counts block");
@@ -1361,7 +1413,8 @@ int tcrc_dev_batch_verify(tcrc_ctx* ctx, const void* d_base, const tcrc_desc* d_
   p.expected = d_expected;
   p.ok = d_ok;
   p.counts = (unsigned long long*)d_counts;
+  p.done = done;
   return run_batch(ctx, p, stream);
 }
 
-}  // extern "C"
+}  // namespace tcrc_internal

@@ -60,13 +60,37 @@ constexpr size_t kZcSuffixOff = kZcDescOff + tcrc_ctx::kZcMaxItems * sizeof(tcrc
 constexpr size_t kZcOutOff = kZcSuffixOff + tcrc_ctx::kZcMaxItems;
 constexpr size_t kZcExpectedOff = kZcOutOff + tcrc_ctx::kZcMaxItems * 4;
 constexpr size_t kZcOkOff = kZcExpectedOff + tcrc_ctx::kZcMaxItems * 4;
-constexpr size_t kZcBytes = kZcOkOff + tcrc_ctx::kZcMaxItems;
+constexpr size_t kZcFlagOff = (kZcOkOff + tcrc_ctx::kZcMaxItems + 63) & ~(size_t)63;  // completion word of small calls
+constexpr size_t kZcBytes = kZcFlagOff + 64;
 // Above this many input bytes a copy to HBM pays for itself (the kernel reads host memory at link speed).
 constexpr size_t kZcMaxInput = (size_t)1 << 20;
 
 int zc_begin(tcrc_lane* L) {
-  if (!L->zc) HIP_TRY(hipHostMalloc((void**)&L->zc, kZcBytes, hipHostMallocMapped | hipHostMallocCoherent));
+  if (!L->zc) {
+    HIP_TRY(hipHostMalloc((void**)&L->zc, kZcBytes, hipHostMallocMapped | hipHostMallocCoherent));
+    memset(L->zc + kZcFlagOff, 0, 64);
+  }
   return TCRC_OK;
+}
+
+// A small call's kernel leaves its results in the lane's zero-copy block and then writes the lane's next
+// sequence number to the block's last word; the call watches that word instead of synchronising the stream.
+int lane_signal(tcrc_ctx* ctx, tcrc_lane* L, DoneSignal* d) {  // after zc_begin
+  *d = DoneSignal{};
+  if (!ctx->poll_completion) return TCRC_OK;
+  if (!L->done_counter) {
+    HIP_TRY(hipMalloc((void**)&L->done_counter, 128));
+    HIP_TRY(hipMemsetAsync(L->done_counter, 0, 128, L->stream));
+  }
+  if (++L->done_seq == 0) ++L->done_seq;
+  d->counter = L->done_counter;
+  d->flag = (uint32_t*)(L->zc + kZcFlagOff);
+  d->value = L->done_seq;
+  return TCRC_OK;
+}
+
+hipError_t lane_wait(tcrc_lane* L, const DoneSignal& d) {
+  return d.flag ? wait_done(d.flag, d.value, L->stream) : hipStreamSynchronize(L->stream);
 }
 
 // True when p is host memory the DMA engines can read directly (allocated or registered pinned);
@@ -299,12 +323,14 @@ int tcrc_host_batch_stamp(tcrc_ctx* ctx, const void* h_base, uint64_t base_bytes
     }
     memcpy(L->zc + kZcDescOff, h_desc, n * sizeof(tcrc_desc));
     if (h_suffix) memcpy(L->zc + kZcSuffixOff, h_suffix, n);
-    if (int rc = tcrc_dev_batch_stamp(ctx, base, (const tcrc_desc*)(L->zc + kZcDescOff), n,
-                                      h_suffix ? (const uint8_t*)(L->zc + kZcSuffixOff) : nullptr, flags,
-                                      (uint32_t*)(L->zc + kZcOutOff), L->stream))
+    DoneSignal done;
+    if (int rc = lane_signal(ctx, L, &done)) return rc;
+    if (int rc = batch_stamp(ctx, base, (const tcrc_desc*)(L->zc + kZcDescOff), n,
+                             h_suffix ? (const uint8_t*)(L->zc + kZcSuffixOff) : nullptr, flags,
+                             (uint32_t*)(L->zc + kZcOutOff), L->stream, done))
       return rc;
     guard.dismiss();
-    HIP_TRY(hipStreamSynchronize(L->stream));
+    HIP_TRY(lane_wait(L, done));
     memcpy(h_out, L->zc + kZcOutOff, n * 4);
     return TCRC_OK;
   }
@@ -412,14 +438,16 @@ int tcrc_host_batch_verify(tcrc_ctx* ctx, const void* h_base, uint64_t base_byte
     if (h_suffix) memcpy(L->zc + kZcSuffixOff, h_suffix, n);
     if (h_expected) memcpy(L->zc + kZcExpectedOff, h_expected, n * 4);
     const uint8_t* ok = (const uint8_t*)(L->zc + kZcOkOff);
-    if (int rc = tcrc_dev_batch_verify(ctx, base, (const tcrc_desc*)(L->zc + kZcDescOff), n,
-                                       h_suffix ? (const uint8_t*)(L->zc + kZcSuffixOff) : nullptr, flags,
-                                       h_expected ? (const uint32_t*)(L->zc + kZcExpectedOff) : nullptr,
-                                       (uint32_t*)(L->zc + kZcOutOff), (uint8_t*)(L->zc + kZcOkOff),
-                                       (uint64_t*)L->aux.p, L->stream))
+    DoneSignal done;
+    if (int rc = lane_signal(ctx, L, &done)) return rc;
+    if (int rc = batch_verify(ctx, base, (const tcrc_desc*)(L->zc + kZcDescOff), n,
+                              h_suffix ? (const uint8_t*)(L->zc + kZcSuffixOff) : nullptr, flags,
+                              h_expected ? (const uint32_t*)(L->zc + kZcExpectedOff) : nullptr,
+                              (uint32_t*)(L->zc + kZcOutOff), (uint8_t*)(L->zc + kZcOkOff), (uint64_t*)L->aux.p,
+                              L->stream, done))
       return rc;
     guard.dismiss();
-    HIP_TRY(hipStreamSynchronize(L->stream));
+    HIP_TRY(lane_wait(L, done));
     if (h_out) memcpy(h_out, L->zc + kZcOutOff, n * 4);
     if (h_ok) memcpy(h_ok, ok, n);
     for (uint64_t i = 0; i < n; ++i)
@@ -566,11 +594,15 @@ int tcrc_extend(tcrc_ctx* ctx, uint32_t init, const void* h_data, size_t n, uint
       base = L->zc;
     }
     ctx->st_host_bytes_in.fetch_add(n, std::memory_order_relaxed);
-    if (int rc = tcrc_dev_blocks_stamp(ctx, base, 1, (uint32_t)n, n, init, -1, nullptr, 0,
-                                       (uint32_t*)(L->zc + kZcOutOff), L->stream))
-      return rc;
+    tcrc_desc* const d = (tcrc_desc*)(L->zc + kZcDescOff);
+    d->offset = 0;
+    d->len = (uint32_t)n;
+    d->init = init;
+    DoneSignal done;
+    if (int rc = lane_signal(ctx, L, &done)) return rc;
+    if (int rc = batch_stamp(ctx, base, d, 1, nullptr, 0, (uint32_t*)(L->zc + kZcOutOff), L->stream, done)) return rc;
     guard.dismiss();
-    HIP_TRY(hipStreamSynchronize(L->stream));
+    HIP_TRY(lane_wait(L, done));
     memcpy(&crc, L->zc + kZcOutOff, 4);
     *out = crc;
     return TCRC_OK;

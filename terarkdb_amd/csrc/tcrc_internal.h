@@ -18,6 +18,17 @@ namespace tcrc_internal {
 constexpr uint32_t kFlagSegments = 0x200u;  // the items are segments of longer buffers (LongArgs): results are shifted and XORed
 constexpr uint32_t kFlagStampBefore = 0x400u;  // the result is also stored as LE32 six bytes before the buffer (log header)
 
+// How a launch tells a waiting host thread that it is done without a hipStreamSynchronize (which costs
+// about 3.5 us more than watching a word of pinned memory): the workgroups (or, for segments of long buffers,
+// the buffers) count themselves off at `counter`, and whoever completes the count zeroes it again and writes
+// `value` to `flag`.  Only for launches whose results go to memory that is not cached on the GPU (pinned host
+// memory), or are written with system-scope stores: the host acts on them the moment it sees the flag.
+struct DoneSignal {
+  uint32_t* counter;  // device memory, zero before and after the launch
+  uint32_t* flag;     // pinned host memory (its device address); NULL: no signal
+  uint32_t value;
+};
+
 struct BatchParams {
   const uint8_t* base;
   const tcrc_desc* desc;  // NULL: uniform geometry below
@@ -37,6 +48,7 @@ struct BatchParams {
   int lanes;                 // lanes per buffer to use (4, 8, 16, 64), 0 = let the engine choose
   const uint32_t* tab_main;  // 1024 dwords: Z_D set
   const uint32_t* tab_aux;   // (1+log2 G) sets of 1024 dwords: Z_4, Z_16, Z_32, ...
+  DoneSignal done;
 };
 
 constexpr int kGeoCount = 4;
@@ -156,6 +168,12 @@ void build_tables(int G, std::vector<uint32_t>* main_tab, std::vector<uint32_t>*
 
 // Launches the batch CRC kernel for the geometry the context prefers.
 int run_batch(tcrc_ctx* ctx, BatchParams p, void* stream);
+// tcrc_dev_batch_stamp / tcrc_dev_batch_verify with a completion word (for results in pinned host memory)
+int batch_stamp(tcrc_ctx* ctx, const void* d_base, const tcrc_desc* d_desc, uint64_t n, const uint8_t* d_suffix,
+                uint32_t flags, uint32_t* d_out, void* stream, const DoneSignal& done);
+int batch_verify(tcrc_ctx* ctx, const void* d_base, const tcrc_desc* d_desc, uint64_t n, const uint8_t* d_suffix,
+                 uint32_t flags, const uint32_t* d_expected, uint32_t* d_out, uint8_t* d_ok, uint64_t* d_counts,
+                 void* stream, const DoneSignal& done);
 // Launches it over the p.n segments that la describes (p.base, p.out and p.n are used).
 int run_segments(tcrc_ctx* ctx, BatchParams p, const LongArgs& la, void* stream);
 // Launches the fused log scan (tables and powers are filled in here).
@@ -188,6 +206,19 @@ struct DeviceScope {
 // Synchronises the stream when the scope is left without dismiss(): copies issued from host memory that is
 // about to be freed or reused (a caller's buffer, a local vector, the staging ring) must not stay in flight
 // behind an error return.
+// Waits for the completion word of a launch (DoneSignal); a launch that takes longer than a few hundred
+// microseconds, or that failed and will never write its word, ends in an ordinary stream synchronisation.
+inline hipError_t wait_done(const uint32_t* h_flag, uint32_t value, hipStream_t s) {
+  const auto give_up = std::chrono::steady_clock::now() + std::chrono::microseconds(300);
+  for (;;) {
+    for (int i = 0; i < 64; ++i) {
+      if (__atomic_load_n(h_flag, __ATOMIC_ACQUIRE) == value) return hipSuccess;
+      __builtin_ia32_pause();
+    }
+    if (std::chrono::steady_clock::now() >= give_up) return hipStreamSynchronize(s);
+  }
+}
+
 struct StreamGuard {
   hipStream_t s;
   bool armed = true;
@@ -221,6 +252,8 @@ struct tcrc_lane {
   hipStream_t stream = nullptr;
   tcrc_scratch data, desc, out, aux, blocks, records;
   char* zc = nullptr;
+  uint32_t* done_counter = nullptr;  // device word for the lane's launches that signal their completion
+  uint32_t done_seq = 0;             // value the next such launch writes (never 0)
 };
 
 struct tcrc_ctx {
@@ -248,6 +281,9 @@ struct tcrc_ctx {
   tcrc_scratch long_in, long_acc;
   const uint32_t* d_pow = nullptr;  // kPowTables x kPowEntries words on this GPU (shared by its contexts, never freed)
   uint32_t* d_static = nullptr;     // this GPU's copy of the library's static scratch (accumulator lines first)
+  uint32_t* long_flag = nullptr;    // pinned word the long-buffer kernel writes its completion to (long_mu)
+  uint32_t long_seq = 0;
+  bool poll_completion = true;      // TCRC_NO_POLL=1: always hipStreamSynchronize (for comparison)
   char* long_pin = nullptr;         // pinned staging for the descriptors of a call with more than kLongInline buffers
   // Layout constants of a lane's zero-copy block (tcrc_lane::zc)
   static constexpr size_t kZcData = (size_t)64 << 10;     // bounce area for short pageable inputs

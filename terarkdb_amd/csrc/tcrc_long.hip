@@ -143,6 +143,16 @@ int plan_inline(const tcrc_ctx* ctx, const tcrc_desc* h_desc, uint32_t n, uint32
   return TCRC_OK;
 }
 
+// The context's accumulator lines (one per buffer of a launch) and, behind them, the line that holds the
+// completion count; all zero between launches.
+int acc_reserve(tcrc_ctx* ctx, hipStream_t s) {
+  const size_t bytes = ((size_t)kLongLdsBuffers + 1) * 128;
+  if (ctx->long_acc.bytes >= bytes) return TCRC_OK;
+  if (int rc = scratch_reserve(ctx, &ctx->long_acc, bytes)) return rc;
+  HIP_TRY(hipMemsetAsync(ctx->long_acc.p, 0, ctx->long_acc.bytes, s));
+  return TCRC_OK;
+}
+
 }  // namespace
 
 extern "C" int tcrc_dev_extend_long(tcrc_ctx* ctx, const void* d_base, const tcrc_desc* h_desc, uint64_t n,
@@ -164,14 +174,21 @@ extern "C" int tcrc_dev_extend_long(tcrc_ctx* ctx, const void* d_base, const tcr
     std::lock_guard<std::mutex> lock(ctx->long_mu);  // the accumulator lines belong to one call at a time
     ctx->st_long_calls.fetch_add(1, std::memory_order_relaxed);
     ctx->st_long_bytes.fetch_add(total, std::memory_order_relaxed);
-    if (ctx->long_acc.bytes < (size_t)kLongInline * 128) {
-      if (int rc = scratch_reserve(ctx, &ctx->long_acc, (size_t)kLongLdsBuffers * 128)) return rc;
-      HIP_TRY(hipMemsetAsync(ctx->long_acc.p, 0, ctx->long_acc.bytes, s));
-    }
+    if (int rc = acc_reserve(ctx, s)) return rc;
     la.acc = (uint32_t*)ctx->long_acc.p;
     p.n = nseg;
+    // "returns with d_out complete", which also frees the lines for the next call: the kernel writes a word
+    // of pinned memory when the last buffer's result is out, and the call watches that word
+    if (ctx->poll_completion && !ctx->long_flag)
+      HIP_TRY(hipHostMalloc((void**)&ctx->long_flag, 64, hipHostMallocMapped | hipHostMallocCoherent));
+    if (ctx->long_flag) {
+      if (++ctx->long_seq == 0) ++ctx->long_seq;
+      p.done.counter = (uint32_t*)ctx->long_acc.p + (size_t)kLongLdsBuffers * 32;  // the line behind the accumulators
+      p.done.flag = ctx->long_flag;  // (mapped memory: one address for host and device)
+      p.done.value = ctx->long_seq;
+    }
     if (int rc = run_segments(ctx, p, la, stream)) return rc;
-    HIP_TRY(hipStreamSynchronize(s));  // "returns with d_out complete"; also frees the lines for the next call
+    HIP_TRY(ctx->long_flag ? wait_done(ctx->long_flag, ctx->long_seq, s) : hipStreamSynchronize(s));
     return TCRC_OK;
   }
 
@@ -212,10 +229,7 @@ extern "C" int tcrc_dev_extend_long(tcrc_ctx* ctx, const void* d_base, const tcr
   first[n] = (uint32_t)nseg;
   if (nseg >= (1ull << 31)) return fail(TCRC_ERR_TOO_LARGE, "too many segments");
   if (int rc = scratch_reserve(ctx, &ctx->long_in, in_bytes)) return rc;
-  if (ctx->long_acc.bytes < (size_t)kLongLdsBuffers * 128) {
-    if (int rc = scratch_reserve(ctx, &ctx->long_acc, (size_t)kLongLdsBuffers * 128)) return rc;
-    HIP_TRY(hipMemsetAsync(ctx->long_acc.p, 0, ctx->long_acc.bytes, s));
-  }
+  if (int rc = acc_reserve(ctx, s)) return rc;
   StreamGuard guard(s);  // the staging must not be left with a copy in flight
   HIP_TRY(hipMemcpyAsync(ctx->long_in.p, stage, in_bytes, hipMemcpyHostToDevice, s));
   const tcrc_desc* d_bufs = (const tcrc_desc*)ctx->long_in.p;

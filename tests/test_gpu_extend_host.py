@@ -105,3 +105,34 @@ def test_file_checksum_and_copy(eng, tmp_path):
                                       C.byref(size), msg, 512)
     assert (rc, crc.value, size.value) == (0, O.value(data[:limit], variant="hw"), limit)
     assert os.path.getsize(dst) == limit
+
+
+def test_back_to_back_small_calls_return_their_own_results(eng):
+    # a small call returns when its kernel has written the completion word, not after a stream
+    # synchronisation: thousands of calls in a row, each result checked, sizes changing from call to call
+    rng = np.random.default_rng(77)
+    pool = rng.integers(0, 256, 1 << 16, dtype=np.uint8).tobytes()
+    for i in range(3000):
+        n = int(rng.integers(1, 9000))
+        o = int(rng.integers(0, len(pool) - n))
+        init = int(rng.integers(0, 1 << 32))
+        assert eng.extend(init, pool[o:o + n]) == O.extend(init, pool[o:o + n]), (i, n, o)
+
+
+def test_back_to_back_small_batches_of_changing_size(eng):
+    # the same for descriptor batches that span one to many workgroups
+    import terarkdb_amd.capi as capi
+    rng = np.random.default_rng(78)
+    image = rng.integers(0, 256, 60000, dtype=np.uint8)  # short enough to go through the zero-copy block
+    for i in range(400):
+        n = int(rng.integers(1, 700))
+        lens = rng.integers(0, 1400, n).astype(np.uint32)
+        offs = rng.integers(0, image.size - 1400, n).astype(np.uint64)
+        inits = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+        d = (capi.Desc * n)()
+        for k in range(n):
+            d[k].offset, d[k].len, d[k].init = int(offs[k]), int(lens[k]), int(inits[k])
+        out = (C.c_uint32 * n)()
+        assert capi.lib.tcrc_host_batch_stamp(eng.ctx, image.ctypes.data, image.size, d, n, None, capi.F_MASK, out) == 0
+        want = O.batch_extend(image, offs, lens, inits, None, True)
+        assert (np.frombuffer(out, dtype=np.uint32) == want).all(), i
