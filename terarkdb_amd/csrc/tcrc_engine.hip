@@ -23,6 +23,7 @@
 // (table/block_based_table_builder.cc:598-601) and the verify comparisons of
 // table/block_fetcher.cc:41-48,64 and db/log_reader.cc:388-390.
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -347,6 +348,11 @@ __device__ __forceinline__ uint32_t span_remainder(const uint32_t* lds, uint32_t
   return reg;
 }
 
+// where the second kernel argument starts in the argument block
+constexpr size_t kLongArgsOffset = (sizeof(BatchParams) + alignof(LongArgs) - 1) / alignof(LongArgs) * alignof(LongArgs);
+static_assert(sizeof(tcrc_desc) == 16 && offsetof(LongArgs, inl) % 16 == 0 && kLongArgsOffset % 16 == 0,
+              "descriptors in the kernel arguments are fetched as 16-byte words");
+
 template <bool SEG> struct SegArgs { typedef NoLongArgs type; };
 template <> struct SegArgs<true> { typedef LongArgs type; };
 
@@ -401,17 +407,17 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p, typename 
   if constexpr (SEG) {
     if (la.seg_first) {
       for (uint32_t i = tid; i <= la.nbuf; i += kThreads) seg_first_lds[i] = la.seg_first[i] - la.first_base;
-    } else if (tid == 0) {
-      // constant indices only: the argument block stays in scalar registers
-#pragma unroll
-      for (int i = 0; i < kLongInline; ++i) {
-        if (i < (int)la.nbuf) {
-          seg_first_lds[i] = la.inl_first[i];
-          seg_inl_lds[i] = make_uint4((uint32_t)la.inl[i].offset, (uint32_t)(la.inl[i].offset >> 32), la.inl[i].len,
-                                      la.inl[i].init);
-        }
+    } else {
+      // Descriptors that came in the kernel arguments go to LDS, where they can be indexed.  The argument
+      // block is ordinary memory: thread i fetches descriptor i from it with vector loads (walking the
+      // arguments with constant indices on one thread instead costs about 2 us for 64 buffers, with every
+      // other wave waiting at the barrier below).
+      const uint8_t* args = (const uint8_t*)__builtin_amdgcn_kernarg_segment_ptr() + kLongArgsOffset;
+      if ((uint32_t)tid < la.nbuf) {
+        seg_inl_lds[tid] = *(const uint4*)(args + offsetof(LongArgs, inl) + (size_t)tid * sizeof(tcrc_desc));
+        seg_first_lds[tid] = *(const uint32_t*)(args + offsetof(LongArgs, inl_first) + (size_t)tid * 4u);
       }
-      seg_first_lds[la.nbuf] = (uint32_t)p.n;  // all segments of the launch
+      if (tid == 0) seg_first_lds[la.nbuf] = (uint32_t)p.n;  // all segments of the launch
     }
   }
   __syncthreads();
@@ -431,12 +437,29 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p, typename 
     n = nd < n ? nd : n;
   }
   const uint64_t nrounds = (n + GPW - 1) / GPW;
+  // SEG: what this wave has gathered for one buffer and not yet delivered
+  uint32_t pend_owner = 0, pend_total = 0, pend_value = 0, pend_count = 0;
 
   // the descriptor of the next round is fetched while the current round runs
   tcrc_desc d_next = {0, 0, 0};
   if (p.desc && wave < nrounds && wave * GPW + grp < n) d_next = p.desc[wave * GPW + grp];
 
-  for (uint64_t round = wave; round < nrounds; round += nwaves) {
+  // Which rounds this wave takes.  Independent buffers: round wave, wave + nwaves, ... (dealt to workgroups
+  // first, then to the waves of a workgroup, so that a small batch still spreads over all CUs).  Segments of
+  // long buffers: a run of consecutive rounds, and consecutive runs for the waves of a workgroup - what a
+  // wave, and then a workgroup, gathers is then mostly for one buffer and reaches that buffer's accumulator
+  // line as one arrival.
+  uint64_t round_first = wave, round_last = nrounds, round_step = nwaves;
+  if constexpr (SEG) {
+    const uint64_t per_wg = (nrounds + gridDim.x - 1) / gridDim.x;
+    const uint64_t wpw = per_wg < (uint64_t)kWavesPerWg ? per_wg : (uint64_t)kWavesPerWg;  // active waves per workgroup
+    const uint64_t k = (nrounds + (uint64_t)gridDim.x * wpw - 1) / ((uint64_t)gridDim.x * wpw);
+    const uint64_t w = (uint64_t)blockIdx.x * wpw + (uint64_t)(tid >> 6);
+    round_step = 1;
+    round_first = (uint64_t)(tid >> 6) < wpw ? w * k : nrounds;
+    round_last = round_first + k < nrounds ? round_first + k : nrounds;
+  }
+  for (uint64_t round = round_first; round < round_last; round += round_step) {
     const uint64_t buf = round * GPW + grp;
     const bool valid = buf < n;
     uint64_t off = 0;
@@ -447,7 +470,7 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p, typename 
       const uint64_t nb = (round + nwaves) * GPW + grp;
       if (round + nwaves < nrounds && nb < n) d_next = p.desc[nb];
     }
-    uint32_t seg_owner = 0, seg_after = 0, seg_total = 0;
+    uint32_t seg_owner = 0, seg_after = 0, seg_total = 0, seg_pow_lo = 0, seg_pow_hi = 0;
     if constexpr (SEG) {
       if (valid) {
         // buffer that owns segment `buf`: the last b with seg_first[b] <= buf
@@ -476,6 +499,11 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p, typename 
         off = bd.offset + start;
         len = (uint32_t)(end - start);
         init = sidx == f0 ? bd.init : 0xffffffffu;  // later segments start from a zero register
+        // the powers this segment's remainder will be multiplied by are fetched now, behind the row loop
+        if (j == G - 1) {
+          seg_pow_lo = la.pow_lo[seg_after & (kPowEntries - 1)];
+          if (seg_after >= (uint32_t)kPowEntries) seg_pow_hi = la.pow_hi[seg_after >> 11];
+        }
       }
     } else if (valid) {
       if (p.desc) {
@@ -523,8 +551,8 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p, typename 
         // enters the buffer's remainder advanced through q * segment_len bytes: x^(8 S q) is the product of
         // one entry of each level of the power table.  The final inversion rides on the last segment (q == 0).
         const uint32_t q = seg_after;
-        uint32_t prod = gf2_mulmod_dev(reg, la.pow_lo[q & (kPowEntries - 1)]);
-        if (q >= (uint32_t)kPowEntries) prod = gf2_mulmod_dev(prod, la.pow_hi[q >> 11]);
+        uint32_t prod = gf2_mulmod_dev(reg, seg_pow_lo);
+        if (q >= (uint32_t)kPowEntries) prod = gf2_mulmod_dev(prod, seg_pow_hi);
         seg_value = q == 0 ? ~prod : prod;
         seg_have = true;
       } else {
@@ -561,15 +589,61 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p, typename 
         uint32_t v = seg_have ? seg_value : 0u;
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) v ^= __shfl_xor(v, o);
-        if (lane == 0 && have)
-          seg_arrive(la.acc + (uint64_t)first_owner * 32u, v, (uint32_t)__popcll(have), first_total,
-                     p.out + first_owner, p.done, la.nbuf);
+        if (have) {
+          // kept until the wave meets another buffer, or the launch ends
+          if (pend_count && pend_owner != first_owner) {
+            if (lane == 0)
+              seg_arrive(la.acc + (uint64_t)pend_owner * 32u, pend_value, pend_count, pend_total, p.out + pend_owner,
+                         p.done, la.nbuf);
+            pend_value = 0;
+            pend_count = 0;
+          }
+          pend_owner = first_owner;
+          pend_total = first_total;
+          pend_value ^= v;
+          pend_count += (uint32_t)__popcll(have);
+        }
       } else if (seg_have) {
         seg_arrive(la.acc + (uint64_t)seg_owner * 32u, seg_value, 1u, seg_total, p.out + seg_owner, p.done, la.nbuf);
       }
     }
   }
   if (p.verify && blockIdx.x == 0 && tid == 0) atomicAdd(&p.counts[TCRC_CNT_CHECKED], (unsigned long long)n);
+  if constexpr (SEG) {
+    // What the waves still hold meets in LDS: when it is all for one buffer (the usual case) the workgroup
+    // arrives at that buffer's line once.
+    __shared__ uint32_t fold[kWavesPerWg][4];
+    if (lane == 0) {
+      fold[tid >> 6][0] = pend_owner;
+      fold[tid >> 6][1] = pend_value;
+      fold[tid >> 6][2] = pend_count;
+      fold[tid >> 6][3] = pend_total;
+    }
+    __syncthreads();
+    if (tid < 64) {
+      const int w = lane < kWavesPerWg ? lane : 0;
+      const uint32_t owner = fold[w][0], total = fold[w][3];
+      uint32_t v = fold[w][1], c = lane < kWavesPerWg ? fold[w][2] : 0u;
+      const unsigned long long act = __ballot(c != 0u);
+      if (act) {
+        const int first = __ffsll((long long)act) - 1;
+        const uint32_t first_owner = __shfl(owner, first), first_total = __shfl(total, first);
+        if (__all(c == 0u || owner == first_owner)) {
+          if (c == 0u) v = 0u;
+#pragma unroll
+          for (int o = kWavesPerWg / 2; o >= 1; o >>= 1) {
+            v ^= __shfl_xor(v, o);
+            c += __shfl_xor(c, o);
+          }
+          if (lane == 0)
+            seg_arrive(la.acc + (uint64_t)first_owner * 32u, v, c, first_total, p.out + first_owner, p.done,
+                       la.nbuf);
+        } else if (c != 0u) {
+          seg_arrive(la.acc + (uint64_t)owner * 32u, v, c, total, p.out + owner, p.done, la.nbuf);
+        }
+      }
+    }
+  }
   if constexpr (!SEG) {
     if (p.done.flag) {
       // Every wave's stores have been acknowledged by the L2 at the barrier; a system-scope release by one
@@ -1077,7 +1151,13 @@ int run_segments(tcrc_ctx* ctx, BatchParams p, const LongArgs& la, void* stream)
   p.flags = kFlagSegments;
   p.uniform_suffix = -1;
   const uint64_t rounds = (p.n + (64 / G) - 1) / (64 / G);
-  const unsigned wgs = (unsigned)(rounds < (uint64_t)ctx->cus ? rounds : (uint64_t)ctx->cus);
+  // A small launch spreads over 64 workgroups first (a CU alone pulls its bytes slowly), then fills their
+  // sixteen waves, then takes more workgroups: every workgroup ends with one arrival at an accumulator line,
+  // and arrivals at one line queue (about 20 ns each).
+  uint64_t wgs64 = rounds < 64 ? rounds : 64;
+  const uint64_t filled = (rounds + kWavesPerWg - 1) / kWavesPerWg;
+  if (filled > wgs64) wgs64 = filled;
+  const unsigned wgs = (unsigned)(wgs64 < (uint64_t)ctx->cus ? wgs64 : (uint64_t)ctx->cus);
   ctx->st_batch_launches.fetch_add(1, std::memory_order_relaxed);
   ctx->st_batch_buffers.fetch_add(p.n, std::memory_order_relaxed);
   hipStream_t s = (hipStream_t)stream;

@@ -112,18 +112,18 @@ constexpr int kPowMinShift = 8;         // smallest segment: 256 bytes
 constexpr int kPowMaxShift = 30;        // largest: 1 GiB
 constexpr int kPowEntries = 2048;       // table T_s holds x^(8 * 2^s * i) for i < 2048
 constexpr int kPowTables = kPowMaxShift + 11 - kPowMinShift + 1;  // T_8 .. T_41: T_(s+11) is T_s's second level
-struct LongArgs {
+struct alignas(16) LongArgs {
+  tcrc_desc inl[kLongInline];  // first, and 16-byte aligned: the kernel fetches them from the argument block
+  uint32_t inl_first[kLongInline];
   uint32_t nbuf;              // buffers of this launch (<= kLongLdsBuffers)
   uint32_t seg_shift;         // log2 of the segment length
   uint32_t first_base;        // value of seg_first[0] (running counts may continue from an earlier launch)
-  const tcrc_desc* bufs;      // [nbuf] in device memory, or NULL: inl / inl_first below
+  const tcrc_desc* bufs;      // [nbuf] in device memory, or NULL: inl / inl_first above
   const uint32_t* seg_first;  // [nbuf + 1] segments before buffer b
   const uint32_t* pow_lo;     // T_seg_shift
   const uint32_t* pow_hi;     // T_(seg_shift + 11)
   uint32_t* acc;              // one 128-byte line per buffer: word 0 XOR of the shifted segment remainders,
                               // word 1 segments arrived.  All zero before and after a launch.
-  tcrc_desc inl[kLongInline];
-  uint32_t inl_first[kLongInline];
 };
 struct NoLongArgs {};
 

@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -57,15 +58,13 @@ __global__ __launch_bounds__(1024) void k_pow_tables(uint32_t* tables) {
   }
 }
 
-// Segment length for a call: a power of two that gives every lane group of the chip (8 per wave, 16 waves
-// per CU) about one segment.  Small totals get shorter segments so that the work still spreads over the
-// CUs, but not more than about a thousand of them: every wave ends with two atomics on its buffer's
-// accumulator line, and those queue up (measured: one 4 MiB buffer takes 25 us with 2 KiB segments and 41 us
-// with 512-byte ones).
+// Segment length for a call: the shortest power of two from 512 bytes up that leaves every lane group of the
+// chip (8 per wave, 16 waves per CU) at most about one segment - short segments spread a small call over many
+// waves, and what the waves of a workgroup deliver to a buffer is folded in LDS before it reaches the buffer's
+// accumulator line, so the arrivals that queue there number segments / 128.
 uint32_t choose_shift(const tcrc_ctx* ctx, uint64_t total) {
   const uint64_t groups = (uint64_t)ctx->cus * 16 * 8;
   uint32_t shift = 9;
-  while (shift < 11 && (total >> shift) > 1024) ++shift;
   while (shift < 16 && (total >> shift) > groups) ++shift;
   return shift;
 }
@@ -179,8 +178,10 @@ extern "C" int tcrc_dev_extend_long(tcrc_ctx* ctx, const void* d_base, const tcr
     p.n = nseg;
     // "returns with d_out complete", which also frees the lines for the next call: the kernel writes a word
     // of pinned memory when the last buffer's result is out, and the call watches that word
-    if (ctx->poll_completion && !ctx->long_flag)
+    if (ctx->poll_completion && !ctx->long_flag) {
       HIP_TRY(hipHostMalloc((void**)&ctx->long_flag, 64, hipHostMallocMapped | hipHostMallocCoherent));
+      *ctx->long_flag = 0;  // the allocator hands back recently freed blocks as they were left
+    }
     if (ctx->long_flag) {
       if (++ctx->long_seq == 0) ++ctx->long_seq;
       p.done.counter = (uint32_t*)ctx->long_acc.p + (size_t)kLongLdsBuffers * 32;  // the line behind the accumulators

@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <utility>
 #include <vector>
 #include "tcrc.h"
 
@@ -78,6 +79,27 @@ int main() {
       hipStreamSynchronize(s);
       us = (now_us() - t0) / K;
       printf("   noalloc, back to back (no wait per call): %.2f us\n", us);
+    }
+  }
+  for (auto shape : {std::pair<int, size_t>(1, size_t(256) << 20), std::pair<int, size_t>(4, size_t(64) << 20),
+                     std::pair<int, size_t>(64, size_t(4) << 20), std::pair<int, size_t>(1, size_t(64) << 20),
+                     std::pair<int, size_t>(16, size_t(1) << 20)}) {
+    const int n = shape.first;
+    const size_t sz = shape.second;
+    std::vector<tcrc_desc> d(n);
+    for (int i = 0; i < n; ++i) { d[i].offset = i * sz; d[i].len = (uint32_t)sz; d[i].init = 0; }
+    for (uint32_t seg : {0u}) {
+      for (int i = 0; i < 300; ++i) tcrc_dev_extend_long(ctx, d_data, d.data(), n, seg, d_out, s);
+      t0 = now_us();
+      for (int i = 0; i < K; ++i) tcrc_dev_extend_long(ctx, d_data, d.data(), n, seg, d_out, s);
+      const double us = (now_us() - t0) / K;
+      printf("tcrc_dev_extend_long %2d x %9zu seg %5u: %.2f us  %.1f GB/s\n", n, sz, seg, us, n * sz / us / 1e3);
+      if (seg == 0) {
+        t0 = now_us();
+        for (int i = 0; i < K; ++i) tcrc_dev_extend_long_noalloc(ctx, d_data, d.data(), n, seg, d_out, s);
+        hipStreamSynchronize(s);
+        printf("   noalloc, back to back (no wait per call): %.2f us\n", (now_us() - t0) / K);
+      }
     }
   }
   tcrc_shutdown(ctx);
