@@ -353,6 +353,19 @@ constexpr size_t kLongArgsOffset = (sizeof(BatchParams) + alignof(LongArgs) - 1)
 static_assert(sizeof(tcrc_desc) == 16 && offsetof(LongArgs, inl) % 16 == 0 && kLongArgsOffset % 16 == 0,
               "descriptors in the kernel arguments are fetched as 16-byte words");
 
+// The main lookup set goes from its 4 KiB in global memory into its 32 replicas in LDS.  Dword i of the set:
+// pair i / 16384, entry (i / 64) mod 256, table of the pair (i / 32) mod 2, replica i mod 32 - so four
+// consecutive dwords hold one value: a thread fetches it once and writes sixteen bytes.
+__device__ __forceinline__ void fill_main_tables(uint32_t* lds, const uint32_t* tab_main, int tid) {
+  static_assert(kMainDwords % (4 * kThreads) == 0, "whole passes");
+#pragma unroll
+  for (int q = tid; q < kMainDwords / 4; q += kThreads) {
+    const int i = q * 4;
+    const uint32_t v = tab_main[((i >> 14) * 2 + ((i >> 5) & 1)) * 256 + ((i >> 6) & 255)];
+    reinterpret_cast<uint4*>(lds)[q] = make_uint4(v, v, v, v);
+  }
+}
+
 template <bool SEG> struct SegArgs { typedef NoLongArgs type; };
 template <> struct SegArgs<true> { typedef LongArgs type; };
 
@@ -393,17 +406,17 @@ template <int G, bool NT, bool SEG>
 __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p, typename SegArgs<SEG>::type la) {
   constexpr int GPW = 64 / G;  // groups (buffers) per wave
   constexpr int kAuxDwords = AuxDwords<G>::value;
-  __shared__ uint32_t lds[kMainDwords + kAuxDwords];
+  __shared__ __align__(16) uint32_t lds[kMainDwords + kAuxDwords];
   // SEG: segments before every buffer of the launch, and the descriptors that came in the kernel arguments
   __shared__ uint32_t seg_first_lds[SEG ? kLongLdsBuffers + 1 : 1];
   __shared__ uint4 seg_inl_lds[SEG ? kLongInline : 1];
 
   const int tid = threadIdx.x;
   if (p.n_dev && *p.n_dev == 0) return;  // an empty list (uniform over the grid): nothing to set up
-  // dword i of the main set: pair i / 16384, entry (i / 64) mod 256, table of the pair (i / 32) mod 2
-  for (int i = tid; i < kMainDwords; i += kThreads)
-    lds[i] = p.tab_main[((i >> 14) * 2 + ((i >> 5) & 1)) * 256 + ((i >> 6) & 255)];
-  for (int i = tid; i < kAuxDwords; i += kThreads) lds[kMainDwords + i] = p.tab_aux[i];
+  fill_main_tables(lds, p.tab_main, tid);
+  static_assert(kAuxDwords % 4 == 0, "the small sets are copied sixteen bytes at a time");
+  for (int q = tid; q < kAuxDwords / 4; q += kThreads)
+    reinterpret_cast<uint4*>(lds + kMainDwords)[q] = reinterpret_cast<const uint4*>(p.tab_aux)[q];
   if constexpr (SEG) {
     if (la.seg_first) {
       for (uint32_t i = tid; i <= la.nbuf; i += kThreads) seg_first_lds[i] = la.seg_first[i] - la.first_base;
@@ -726,7 +739,7 @@ template <bool NT>
 __global__ __launch_bounds__(kThreads) void k_wal_fused(WalScanParams p) {
   constexpr int G = 8;
   constexpr int kAuxDwords = AuxDwords<G>::value;
-  __shared__ uint32_t lds[kMainDwords + kAuxDwords];
+  __shared__ __align__(16) uint32_t lds[kMainDwords + kAuxDwords];
   __shared__ uint2 ring[kWalRingRounds * 8];
   __shared__ uint32_t seq[kWalRingRounds];
   __shared__ WalSlot slots[kWalSlots];
@@ -740,9 +753,10 @@ __global__ __launch_bounds__(kThreads) void k_wal_fused(WalScanParams p) {
     if (p.trace && tid == 0 && at < 32u) p.trace[blockIdx.x * 32u + at] = wall_clock64();
   };
   stamp(0);
-  for (int i = tid; i < kMainDwords; i += kThreads)
-    lds[i] = p.tab_main[((i >> 14) * 2 + ((i >> 5) & 1)) * 256 + ((i >> 6) & 255)];
-  for (int i = tid; i < kAuxDwords; i += kThreads) lds[kMainDwords + i] = p.tab_aux[i];
+  fill_main_tables(lds, p.tab_main, tid);
+  static_assert(kAuxDwords % 4 == 0, "the small sets are copied sixteen bytes at a time");
+  for (int q = tid; q < kAuxDwords / 4; q += kThreads)
+    reinterpret_cast<uint4*>(lds + kMainDwords)[q] = reinterpret_cast<const uint4*>(p.tab_aux)[q];
   for (uint32_t i = tid; i < kWalRingRounds; i += kThreads) seq[i] = i;
   for (int i = tid; i < kWalSlots; i += kThreads) slots[i].remaining = 0u;
   if (tid == 0) {
