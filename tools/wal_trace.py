@@ -43,3 +43,11 @@ for k in range(32):
     if np.isnan(col).all():
         continue
     print(f"{names.get(k, str(k)):18s} {np.nanmin(col):7.1f} {np.nanmedian(col):7.1f} {np.nanmax(col):7.1f}   ({int((~np.isnan(col)).sum())} wgs)")
+if len(sys.argv) > 2:
+    np.save(sys.argv[2], us)
+    order = np.argsort(us[:, 31])
+    print("workgroups by end time: wg, tables, walk over, end")
+    for w in list(order[:5]) + list(order[-12:]):
+        print(f"  {w:4d} {us[w,1]:6.1f} {us[w,2]:6.1f} {us[w,31]:6.1f}")
+    print("correlation(walk over, end) =", np.corrcoef(us[:, 2], us[:, 31])[0, 1])
+    print("end - walk over: min/median/max", np.min(us[:, 31] - us[:, 2]), np.median(us[:, 31] - us[:, 2]), np.max(us[:, 31] - us[:, 2]))
