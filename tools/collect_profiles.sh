@@ -22,7 +22,7 @@ echo "configs plain done"
 # name:kernel-substring:extra arguments
 for spec in log_2k:k_wal_fused: log_mixed:k_wal_fused: log_mixed_recyclable:k_wal_fused: \
             blocks4k_var_verify:k_crc_batch:--phase=verify blocks4k_var_stamp:k_crc_batch:--phase=stamp \
-            blocks8k_var_stamp:k_crc_batch:--phase=stamp spans_2k:k_crc_batch: long_64x4m:k_crc_batch: long_single:k_crc_batch: ; do
+            blocks8k_var_verify:k_crc_batch:--phase=verify blocks8k_var_stamp:k_crc_batch:--phase=stamp spans_2k:k_crc_batch: long_64x4m:k_crc_batch: long_single:k_crc_batch: ; do
   name=${spec%%:*}; rest=${spec#*:}; needle=${rest%%:*}; extra=${rest#*:}
   only=${name%_verify}; only=${only%_stamp}
   timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/kt_$name -o kt -- python3 tools/measure_configs.py --only $only $extra --launches 30 --settle 1.0 > $O/kt_$name.log 2>&1

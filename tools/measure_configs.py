@@ -10,8 +10,8 @@ the CPU oracle (checker only: nothing here times it).
 Names: log_2k (the 1M-record db_bench log, 2.05 GB), log_mixed, log_mixed_recyclable (256 MiB, sizes
 Random(301).Skewed(17)), blocks4k_var, blocks8k_var (1 GiB of table-builder-sized blocks packed with their
 trailers: verify against, and stamp into, the image), spans_2k (the batch kernel alone on 2046-byte spans at
-every alignment), long_64x4m (64 buffers of 4 MiB in one call), long_single (one buffer of 256 KiB / 1 MiB /
-4 MiB per call, host call to completion).  Under rocprofv3 run one name at a time.
+every alignment), long_64x4m (64 buffers of 4 MiB in one call, and one buffer of 256 MiB), long_single (one
+buffer of 256 KiB / 1 MiB / 4 MiB per call, host call to completion).  Under rocprofv3 run one name at a time.
 """
 import argparse
 import ctypes as C
@@ -159,8 +159,8 @@ def run_long(eng, only_single):
     dS = torch.from_numpy(S).cuda()
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     L = capi.lib
-    for n, sizes in ((1, (256 << 10, 1 << 20, 4 << 20)), (64, (4 << 20,))):
-        if (n == 1) != only_single:
+    for n, sizes, single in ((1, (256 << 10, 1 << 20, 4 << 20), True), (64, (4 << 20,), False), (1, (256 << 20,), False)):
+        if single != only_single:
             continue
         for sz in sizes:
             d = (capi.Desc * n)()

@@ -398,7 +398,7 @@ def main():
         long_res[str(sz)] = {"single_us": round(t1 * 1e6, 1), "single_GBps": round(sz / t1 / 1e9, 1),
                              "batch64_us": round(t64 * 1e6, 1), "batch64_GBps": round(64 * sz / t64 / 1e9, 1)}
     res["config4_long_buffers"] = long_res
-    res["config4_note"] = "host call to completion (one kernel launch, one stream synchronisation; descriptors of more than 64 buffers are copied first); device-resident data"
+    res["config4_note"] = "host call to completion, 20 calls after an idle period (clocks down, Python binding); tools/measure_configs.py and tools/floor_probe.hip have the settled figures; device-resident data"
 
     os.makedirs(os.path.dirname(out_path), exist_ok=True)
     json.dump(res, open(out_path, "w"), indent=1)

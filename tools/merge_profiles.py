@@ -51,18 +51,19 @@ for l in open(os.path.join(src, "configs.jsonl")):
     key = {"long_64x4096k": "long_64x4m"}.get(name, name)
     if name.startswith("long_1x"):
         key = "long_single"
-    if key.startswith("blocks8k_var_verify"):
-        key = None  # only the stamp of the 8 KiB shape was profiled
+    shared_run = name.startswith("long_1x")  # several shapes in one profiled command: no per-shape kernel average
+    if name == "long_1x262144k":
+        key = "long_64x4m"  # measured in the same command as the 64 x 4 MiB shape
     needle = "k_wal_fused" if name.startswith("log_") else "k_crc_batch"
     if key:
         cp(f"{key}_kernel_stats.csv", f"{rnd}_{key}_kernel_stats.csv")
         cp(f"{key}_hbm_traffic.json", f"{rnd}_{key}_hbm_traffic.json")
         avg, calls = trace_avg(os.path.join(src, f"{key}_kernel_stats.csv"), needle)
-        if avg is not None and not name.startswith("long_1x"):
+        if avg is not None and not shared_run:
             d["roofline"]["rocprofv3_kernel_avg_us"] = avg
             d["roofline"]["rocprofv3_kernel_calls"] = calls
         t = os.path.join(src, f"{key}_hbm_traffic.json")
-        if os.path.exists(t) and not name.startswith("long_1x"):
+        if os.path.exists(t) and not shared_run:
             d["roofline"]["traffic"] = json.load(open(t)).get("bytes_per_launch")
         d["evidence"] = [f"profiles/{rnd}_{key}_kernel_stats.csv", f"profiles/{rnd}_{key}_hbm_traffic.json"]
     out.append(d)
