@@ -103,3 +103,30 @@ def test_running_totals():
     assert capi.lib.tcrc_reset_stats(eng.ctx) == 0
     assert all(v == 0 for k, v in eng.stats().items() if k != "host_lanes")
     eng.close()
+
+
+def test_calls_that_wait_with_a_stream_synchronisation_give_the_same_results():
+    """TCRC_NO_POLL=1 makes short calls wait with hipStreamSynchronize instead of watching the kernel's completion
+    word; the results must not depend on it (a fresh process: the setting is read when a context is created)."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = r"""
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np
+import oracle_lib as O
+import terarkdb_amd.capi as capi
+eng = capi.Engine(0)
+rng = np.random.default_rng(5)
+pool = rng.integers(0, 256, 1 << 22, dtype=np.uint8)
+for n in (1, 100, 4096, 9000, 70000, 300000, 1 << 22):
+    init = int(rng.integers(0, 1 << 32))
+    assert eng.extend(init, pool[:n]) == O.extend(init, pool[:n].tobytes()), n
+eng.close()
+print("same")
+""" % (os.path.dirname(here), here)
+    env = dict(os.environ, TCRC_NO_POLL="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip().endswith("same"), out.stderr[-2000:]
