@@ -3,6 +3,7 @@
 
 usage: rocprof_summary.py kernel <kt_results.db> <out.csv>
        rocprof_summary.py pmc <fetch_results.db> <write_results.db> <kernel-substring> <out.json>
+       rocprof_summary.py sq <results.db> <kernel-substring> <out.json>
 """
 import json
 import sqlite3
@@ -47,8 +48,31 @@ def pmc(fetch_db, write_db, needle, out):
     print(res)
 
 
+def sq(db, needle, out):
+    """averages per dispatch of whatever SQ counters the pass collected, and the ratios read off them"""
+    c = sqlite3.connect(db)
+    rows = c.execute("select counter_name, avg(value), count(*) from counters_collection where kernel_name like ? "
+                     "group by counter_name", (f"%{needle}%",)).fetchall()
+    v = {name: val for name, val, _ in rows}
+    res = {"kernel": needle, "dispatches": max((n for _, _, n in rows), default=0),
+           "counters_avg_per_dispatch": {k: v[k] for k in sorted(v)}}
+    wc = v.get("SQ_WAVE_CYCLES")
+    if wc:
+        for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS"):
+            if k in v:
+                res[k.lower() + "_per_wave_cycle"] = round(v[k] / wc, 4)
+    if v.get("SQ_LDS_IDX_ACTIVE"):
+        res["lds_bank_conflict_cycles_per_lds_cycle"] = round(v.get("SQ_LDS_BANK_CONFLICT", 0.0) / v["SQ_LDS_IDX_ACTIVE"], 5)
+    res["note"] = ("one rocprofv3 --pmc pass (8 SQ counters); SQ_WAVE_CYCLES, SQ_WAIT_* and SQ_ACTIVE_INST_* count "
+                   "quad-cycles summed over waves; SQ_LDS_BANK_CONFLICT = extra LDS cycles, SQ_LDS_IDX_ACTIVE = all LDS cycles")
+    json.dump(res, open(out, "w"), indent=1)
+    print(res)
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "kernel":
         kernel_stats(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "sq":
+        sq(sys.argv[2], sys.argv[3], sys.argv[4])
     else:
         pmc(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5])
