@@ -804,7 +804,13 @@ __global__ __launch_bounds__(kThreads) void k_wal_fused(WalScanParams p) {
 
   // One step of the walk: every active lane looks at the record under its cursor and, if there is room, puts
   // the record's pieces into the ring.  Returns true if the ring (or the slots) had no room for some record.
-  auto walk_step = [&]() -> bool {
+  // `hdr` is the header under the lane's cursor, fetched by the step before (or by the caller, for a lane that
+  // has none yet); the step leaves the next one in it.
+  auto block_end = [&](uint32_t blk) -> uint64_t {
+    const uint64_t e = (uint64_t)blk * kLogBlockBytes + kLogBlockBytes;
+    return e < p.size ? e : p.size;
+  };
+  auto walk_step = [&](WalHeader& hdr) -> bool {
     const unsigned long long idle = __ballot(!w_active);
     if (idle && w_next < b_hi) {
       const uint32_t nv = w_next + lanes_below(idle);
@@ -815,6 +821,7 @@ __global__ __launch_bounds__(kThreads) void k_wal_fused(WalScanParams p) {
         w_pos = 0;
         w_k = 0;
         p.blocks[nb].first_bad = 0xffffffffu;  // lowered by whoever finds a bad checksum in the block
+        hdr = wal_fetch(p.img, (uint64_t)nb * kLogBlockBytes, block_end(nb));
       }
       const uint32_t handed = w_next + (uint32_t)__popcll(idle);
       w_next = handed < b_hi ? handed : b_hi;
@@ -837,7 +844,12 @@ __global__ __launch_bounds__(kThreads) void k_wal_fused(WalScanParams p) {
     const bool last = p.tail && end == p.size;
     uint32_t hs = 0, len = 0, code = 0;
     bool ok = false;
-    if (w_active) ok = wal_step(p.img, base + w_pos, end, last, p.log_number, &hs, &len, &code);
+    if (w_active) ok = wal_decode(hdr, base + w_pos, end, last, p.log_number, &hs, &len, &code);
+    // The next header is asked for now, before the room for this record is worked out: the walk of a block is a
+    // chain of dependent loads, and the bookkeeping below takes about as long as one of them.  (Should the
+    // record find no room, the lane keeps its header and the fetch was for nothing.)
+    WalHeader nxt = {0u, 0u};
+    if (ok) nxt = wal_fetch(p.img, base + w_pos + hs + len, end);
     if (w_active && !ok) {  // the block's walk ends here: that needs no room in the ring
       tcrc_wal_block* b = p.blocks + w_blk;
       b->n_records = w_k;
@@ -890,6 +902,7 @@ __global__ __launch_bounds__(kThreads) void k_wal_fused(WalScanParams p) {
       }
       w_pos += hs + len;
       ++w_k;
+      hdr = nxt;
     }
     const unsigned long long m_fit = __ballot(fits);
     if (m_fit) {
@@ -929,7 +942,14 @@ __global__ __launch_bounds__(kThreads) void k_wal_fused(WalScanParams p) {
       __builtin_amdgcn_s_setprio(3);  // the walk is the critical path of a workgroup with little to do
       // The walker.  While its records find room it only walks; when they do not, it takes a round itself if one
       // is out that nobody has taken (so that it never waits for a round only it could write).
-      if (!walk_step()) {
+      // (the headers under the cursors are fetched again whenever the walker comes back from other work)
+      WalHeader hdr = {0u, 0u};
+      if (w_active) hdr = wal_fetch(p.img, (uint64_t)w_blk * kLogBlockBytes + w_pos, block_end(w_blk));
+      bool blocked = false;
+      do {
+        blocked = walk_step(hdr);
+      } while (!blocked && !w_done && !lds_load(&ctl[2]));
+      if (!blocked) {
         if (w_done) {
           stamp(2);
           __builtin_amdgcn_s_setprio(0);

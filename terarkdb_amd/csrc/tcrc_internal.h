@@ -56,27 +56,39 @@ constexpr int kGeoCount = 4;
 constexpr uint32_t kLogBlockBytes = 32768;                     // db/log_format.h:37
 constexpr uint32_t kLogHeader = 7, kLogRecyclableHeader = 11;  // db/log_format.h:40,44
 
-// One header step of db/log_reader.cc:317-384.  Returns false when the walk of the block ends
-// (code says why); otherwise the record occupies [pos, pos + hs + len).
-__device__ __forceinline__ bool wal_step(const uint8_t* img, uint64_t pos, uint64_t end, bool last,
-                                         uint64_t log_number, uint32_t* hs_out, uint32_t* len_out,
-                                         uint32_t* code) {
+// One header step of db/log_reader.cc:317-384, in two halves so that a walker can have the next header on its
+// way while it deals with the current record.
+// wal_fetch: bytes 4..10 of the header at pos (length, type, and the log number a recyclable header carries -
+// fetched together with length and type when the bytes are there at all, not after the type has come back:
+// the walk is a chain of dependent loads, and this halves the chain for recyclable logs).
+struct WalHeader {
+  uint32_t len_type;  // length | type byte << 16
+  uint32_t lognum;
+};
+__device__ __forceinline__ WalHeader wal_fetch(const uint8_t* img, uint64_t pos, uint64_t end) {
+  WalHeader h = {0u, 0u};
+  const uint64_t remaining = end - pos;
+  if (remaining >= kLogHeader) {
+    const uint8_t* p = img + pos;
+    h.len_type = (uint32_t)p[4] | ((uint32_t)p[5] << 8) | ((uint32_t)p[6] << 16);
+    if (remaining >= kLogRecyclableHeader)
+      h.lognum = (uint32_t)p[7] | ((uint32_t)p[8] << 8) | ((uint32_t)p[9] << 16) | ((uint32_t)p[10] << 24);
+  }
+  return h;
+}
+// wal_decode: returns false when the walk of the block ends (code says why); otherwise the record occupies
+// [pos, pos + hs + len).
+__device__ __forceinline__ bool wal_decode(const WalHeader& h, uint64_t pos, uint64_t end, bool last, uint64_t log_number,
+                                           uint32_t* hs_out, uint32_t* len_out, uint32_t* code) {
   const uint64_t remaining = end - pos;
   if (remaining < kLogHeader) {
     // a block trailer (zero padding), or at the very end of the file a truncated header
     *code = remaining == 0 ? TCRC_WAL_END_CLEAN : (last ? TCRC_WAL_END_SHORT_AT_EOF : TCRC_WAL_END_TRAILER);
     return false;
   }
-  // The log number of a recyclable header is fetched together with length and type (when the bytes are there
-  // at all), not after the type has come back: the walk is a chain of dependent loads, and this halves the
-  // chain for recyclable logs.
-  const uint8_t* h = img + pos;
   const bool has11 = remaining >= kLogRecyclableHeader;
-  const uint32_t b4 = h[4], b5 = h[5];
-  const uint32_t type = (uint32_t)(int)(signed char)h[6];  // the reference reads it through a char
-  uint32_t lognum = 0;
-  if (has11) lognum = (uint32_t)h[7] | ((uint32_t)h[8] << 8) | ((uint32_t)h[9] << 16) | ((uint32_t)h[10] << 24);
-  const uint32_t len = b4 | (b5 << 8);
+  const uint32_t type = (uint32_t)(int)(signed char)(h.len_type >> 16);  // the reference reads it through a char
+  const uint32_t len = h.len_type & 0xffffu;
   uint32_t hs = kLogHeader;
   if (type >= 5u && type <= 8u) {
     hs = kLogRecyclableHeader;
@@ -84,7 +96,7 @@ __device__ __forceinline__ bool wal_step(const uint8_t* img, uint64_t pos, uint6
       *code = last ? TCRC_WAL_END_SHORT_AT_EOF : TCRC_WAL_END_TRAILER;
       return false;
     }
-    if ((uint64_t)lognum != log_number) {
+    if ((uint64_t)h.lognum != log_number) {
       *code = TCRC_WAL_END_OLD_RECORD;
       return false;
     }
@@ -100,6 +112,11 @@ __device__ __forceinline__ bool wal_step(const uint8_t* img, uint64_t pos, uint6
   *hs_out = hs;
   *len_out = len;
   return true;
+}
+__device__ __forceinline__ bool wal_step(const uint8_t* img, uint64_t pos, uint64_t end, bool last,
+                                         uint64_t log_number, uint32_t* hs_out, uint32_t* len_out,
+                                         uint32_t* code) {
+  return wal_decode(wal_fetch(img, pos, end), pos, end, last, log_number, hs_out, len_out, code);
 }
 
 
