@@ -132,7 +132,10 @@ int tcrc_dev_batch_verify(tcrc_ctx* ctx, const void* d_base, const tcrc_desc* d_
  * in the kernel arguments, more are copied to the GPU first.  Data is on the GPU, the (few) descriptors are on the host.
  * Values are plain CRCs (apply tcrc_mask on the host if a masked value is wanted).
  * Stands in for crc32c::Extend on large inputs (util/crc32c.cc:1226-1228; callers such as
- * utilities/backupable/backupable_db.cc:1434-1449).  Returns with d_out complete. */
+ * utilities/backupable/backupable_db.cc:1434-1449).  Returns with d_out complete: with up to 64 buffers
+ * the call watches a completion word the kernel writes to pinned memory once every result has been written
+ * through to device memory (the stream may still show the kernel as running for a moment; whatever is
+ * enqueued on it afterwards is ordered behind the kernel as usual); with more it synchronises the stream. */
 int tcrc_dev_extend_long(tcrc_ctx* ctx, const void* d_base, const tcrc_desc* h_desc, uint64_t n, uint32_t segment_len,
                          uint32_t* d_out, void* stream);
 
