@@ -718,16 +718,6 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long mask) {
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
-// Sum of v (below 32) over the lanes below this one: one ballot per bit of v and a count of the lower lanes in
-// it - scalar and cheap vector instructions only, where a scan with shuffles takes six trips through the LDS
-// crossbar (the walker's steps are a chain of dependent operations, so their latency is what counts).
-__device__ __forceinline__ uint32_t sum_below_5bit(uint32_t v) {
-  uint32_t sum = 0;
-#pragma unroll
-  for (int b = 0; b < 5; ++b) sum += lanes_below(__ballot((v >> b) & 1u)) << b;
-  return sum;
-}
-
 __device__ __forceinline__ uint32_t lds_load(const uint32_t* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -866,9 +856,25 @@ __global__ __launch_bounds__(kThreads) void k_wal_fused(WalScanParams p) {
     // so.  Only when what is known to be free does not take this step's entries are the sequence numbers looked
     // at again: lane i looks at round w_open + i; the rounds up to the first one that is still somebody's are
     // added.
-    uint32_t step_entries = 0;
+    // Counts and places come from ballots - one per bit of the piece count, and a count of the lower lanes in it:
+    // scalar and cheap vector instructions only, where a scan with shuffles takes six trips through the LDS
+    // crossbar (the walker's steps are a chain of dependent operations, so their latency is what counts).  A step
+    // in which no record is longer than a piece - every step of a log of small records - gets by with one ballot
+    // and does not look at the slots.
+    const unsigned long long m_multi = __ballot(multi);
+    uint32_t step_entries = 0, below_e = 0;
+    if (m_multi == 0ull) {
+      const unsigned long long m_ok = __ballot(ok);
+      step_entries = (uint32_t)__popcll(m_ok);
+      below_e = lanes_below(m_ok);
+    } else {
 #pragma unroll
-    for (int b = 0; b < 5; ++b) step_entries += (uint32_t)__popcll(__ballot((c >> b) & 1u)) << b;
+      for (int b = 0; b < 5; ++b) {
+        const unsigned long long mb = __ballot((c >> b) & 1u);
+        step_entries += (uint32_t)__popcll(mb) << b;
+        below_e += lanes_below(mb) << b;
+      }
+    }
     if (step_entries > w_open * 8u - w_count) {
       const uint32_t t = w_open + (uint32_t)lane;
       const bool mine = (uint32_t)lane < kWalStepRounds && lds_load(&seq[t % kWalRingRounds]) == t;
@@ -879,11 +885,14 @@ __global__ __launch_bounds__(kThreads) void k_wal_fused(WalScanParams p) {
     const uint32_t room = w_open * 8u - w_count;
     // Lanes take room in lane order; those that no longer fit keep their record for the next step.  A span of
     // several pieces also needs its slot to be free.
-    const uint32_t upto_e = sum_below_5bit(c) + c;
-    const uint32_t my_span = w_spans + lanes_below(__ballot(multi));
-    const bool slot_busy = multi && lds_load(&slots[my_span % kWalSlots].remaining) != 0u;
-    const unsigned long long m_busy = __ballot(slot_busy || (multi && my_span - w_spans >= (uint32_t)kWalSlots));
-    const bool before_busy = m_busy == 0ull || lane < __builtin_ctzll(m_busy);
+    const uint32_t upto_e = below_e + c;
+    const uint32_t my_span = w_spans + lanes_below(m_multi);
+    bool before_busy = true;
+    if (m_multi != 0ull) {
+      const bool slot_busy = multi && lds_load(&slots[my_span % kWalSlots].remaining) != 0u;
+      const unsigned long long m_busy = __ballot(slot_busy || (multi && my_span - w_spans >= (uint32_t)kWalSlots));
+      before_busy = m_busy == 0ull || lane < __builtin_ctzll(m_busy);
+    }
     const bool fits = ok && upto_e <= room && before_busy;
     if (fits) {
       const uint32_t slot = multi ? my_span % kWalSlots : kWalNoSlot;
