@@ -62,17 +62,25 @@ constexpr uint32_t kLogHeader = 7, kLogRecyclableHeader = 11;  // db/log_format.
 // fetched together with length and type when the bytes are there at all, not after the type has come back:
 // the walk is a chain of dependent loads, and this halves the chain for recyclable logs).
 struct WalHeader {
-  uint32_t len_type;  // length | type byte << 16
-  uint32_t lognum;
+  uint32_t lo, hi;  // header bytes 4..7 and 8..11 as they lie in memory (byte 11 is payload already)
 };
 __device__ __forceinline__ WalHeader wal_fetch(const uint8_t* img, uint64_t pos, uint64_t end) {
   WalHeader h = {0u, 0u};
   const uint64_t remaining = end - pos;
-  if (remaining >= kLogHeader) {
-    const uint8_t* p = img + pos;
-    h.len_type = (uint32_t)p[4] | ((uint32_t)p[5] << 8) | ((uint32_t)p[6] << 16);
-    if (remaining >= kLogRecyclableHeader)
-      h.lognum = (uint32_t)p[7] | ((uint32_t)p[8] << 8) | ((uint32_t)p[9] << 16) | ((uint32_t)p[10] << 24);
+  const uint8_t* p = img + pos;
+  if (remaining >= 12u) {
+    // one unaligned 8-byte load, and nothing done to the result here: whoever fetches ahead wants the load
+    // in flight, not waited for
+    uint2 w;
+    __builtin_memcpy(&w, p + 4, 8);
+    h.lo = w.x;
+    h.hi = w.y;
+  } else if (remaining >= kLogHeader) {  // the last bytes of a block: byte by byte, never past `end`
+    h.lo = (uint32_t)p[4] | ((uint32_t)p[5] << 8) | ((uint32_t)p[6] << 16);
+    if (remaining >= kLogRecyclableHeader) {
+      h.lo |= (uint32_t)p[7] << 24;
+      h.hi = (uint32_t)p[8] | ((uint32_t)p[9] << 8) | ((uint32_t)p[10] << 16);
+    }
   }
   return h;
 }
@@ -87,8 +95,9 @@ __device__ __forceinline__ bool wal_decode(const WalHeader& h, uint64_t pos, uin
     return false;
   }
   const bool has11 = remaining >= kLogRecyclableHeader;
-  const uint32_t type = (uint32_t)(int)(signed char)(h.len_type >> 16);  // the reference reads it through a char
-  const uint32_t len = h.len_type & 0xffffu;
+  const uint32_t type = (uint32_t)(int)(signed char)(h.lo >> 16);  // the reference reads it through a char
+  const uint32_t len = h.lo & 0xffffu;
+  const uint32_t lognum = (h.lo >> 24) | (h.hi << 8);
   uint32_t hs = kLogHeader;
   if (type >= 5u && type <= 8u) {
     hs = kLogRecyclableHeader;
@@ -96,7 +105,7 @@ __device__ __forceinline__ bool wal_decode(const WalHeader& h, uint64_t pos, uin
       *code = last ? TCRC_WAL_END_SHORT_AT_EOF : TCRC_WAL_END_TRAILER;
       return false;
     }
-    if ((uint64_t)h.lognum != log_number) {
+    if ((uint64_t)lognum != log_number) {
       *code = TCRC_WAL_END_OLD_RECORD;
       return false;
     }
