@@ -735,7 +735,7 @@ __global__ __launch_bounds__(kThreads) void k_wal_fused(WalScanParams p) {
   __shared__ WalSlot slots[kWalSlots];
   // [0] next ticket, [1] rounds in all once the walk is over (till then ~0), [2] set when a wait ran out
   __shared__ uint32_t ctl[4];
-  __shared__ uint32_t pow_piece[16];
+  __shared__ uint32_t pow_piece[64];  // [q * 4 + l]: x^(8 * kWalPiece * q) * x^(8 l)
 
   const int tid = threadIdx.x;
   // trace (development aid): wave 0 notes the time at [0] start, [1] tables in place, [2] walk over, [31] end
@@ -751,7 +751,7 @@ __global__ __launch_bounds__(kThreads) void k_wal_fused(WalScanParams p) {
   for (int i = tid; i < kWalSlots; i += kThreads) slots[i].remaining = 0u;
   if (tid == 0) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) pow_piece[i] = p.pow_piece[i];
+    for (int i = 0; i < 64; ++i) pow_piece[i] = p.pow_piece[i];
     ctl[0] = 0u;
     ctl[1] = 0xffffffffu;
     ctl[2] = 0u;
@@ -1020,6 +1020,25 @@ __global__ __launch_bounds__(kThreads) void k_wal_fused(WalScanParams p) {
     if (valid && first && j == G - 1) __builtin_memcpy(&stored, ptr - 6, 4);
     const uint32_t core = span_remainder<G, NT>(lds, LB, lane, ptr, len, first ? 0u : 0xffffffffu, valid, false,
                                                 (const uint8_t*)p.tab_main);
+    // A piece with q pieces behind it enters its span's remainder multiplied by x^(8 * kWalPiece * q).  The 32
+    // shift-and-xor steps of that multiplication are split over four lanes of the group, like the un-shift in
+    // span_remainder: lane l takes bits [8 l, 8 l + 8) of the remainder against the multiplier times x^(8 l),
+    // which comes from the table.  (One lane doing all 32 steps costs the whole wave four times as long.)
+    uint32_t shifted = core;
+    if (__any(valid && q != 0u)) {
+      const uint32_t rr = __shfl(core, lane | (G - 1));
+      const int l = j & 3;
+      uint32_t b = pow_piece[(q & 15u) * 4u + (uint32_t)l];
+      uint32_t part = 0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        part ^= ((rr >> (31 - 8 * l - k)) & 1u) ? b : 0u;
+        b = (b >> 1) ^ ((b & 1u) ? 0x82f63b78u : 0u);
+      }
+      part ^= __shfl_xor(part, 1);
+      part ^= __shfl_xor(part, 2);
+      if (q != 0u) shifted = part;
+    }
     if (valid && j == G - 1) {
       if (slot == kWalNoSlot) {
         const uint32_t crc = ~core;
@@ -1031,7 +1050,7 @@ __global__ __launch_bounds__(kThreads) void k_wal_fused(WalScanParams p) {
           lds_store(&sl->blk, blk);
           lds_store(&sl->start, start);
         }
-        const uint32_t v = q ? gf2_mulmod_dev(core, pow_piece[q]) : core;
+        const uint32_t v = shifted;
         (void)__hip_atomic_fetch_xor(&sl->acc, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         // release what this piece left in the slot, acquire what the others left
         const uint32_t before = __hip_atomic_fetch_sub(&sl->remaining, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1225,7 +1244,8 @@ int run_wal_scan(tcrc_ctx* ctx, WalScanParams p, void* stream) {
   const int gi = geo_index(8);
   p.tab_main = ctx->d_tab_main[gi];
   p.tab_aux = ctx->d_tab_aux[gi];
-  for (uint32_t q = 0; q < 16; ++q) p.pow_piece[q] = tcrc::gf2_xpow(8ull * kWalPiece * q);
+  for (uint32_t q = 0; q < 16; ++q)
+    for (uint32_t l = 0; l < 4; ++l) p.pow_piece[q * 4 + l] = tcrc::gf2_xpow(8ull * kWalPiece * q + 8ull * l);
   p.trace = (unsigned long long*)ctx->wal_trace;
   // chunks of up to 64 blocks (one per walker lane), at least two chunks per workgroup
   p.chunk_shift = 6;

@@ -170,7 +170,7 @@ struct WalScanParams {
                                      // pinned host memory by the last workgroup to finish
   unsigned long long* launch_words;  // with records_host: two device words, zero before and after a launch
                                      // (records so far, workgroups done)
-  uint32_t pow_piece[16];      // x^(8 * kWalPiece * q) mod P
+  uint32_t pow_piece[64];      // [q * 4 + l]: x^(8 * kWalPiece * q + 8 l) mod P
   unsigned long long* trace;   // development aid, normally NULL: 32 timestamps (100 MHz) per workgroup, see k_wal_fused
   const uint32_t* tab_main;
   const uint32_t* tab_aux;
