@@ -5,7 +5,7 @@ reads), rNN_bench_8gib_shard.json, rNN_<config>_kernel_stats.csv, rNN_<config>_h
 rNN_configs.json: one JSON line per configuration with roofline.traffic filled in from the PMC passes and the
 kernel's average duration in the rocprofv3 trace beside the event-timed one.
 
-usage: merge_profiles.py r02"""
+usage: merge_profiles.py PREFIX   (the prefix the files get, e.g. the collection's label)"""
 import csv
 import glob
 import json
