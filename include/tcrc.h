@@ -57,6 +57,11 @@ typedef struct tcrc_desc {
                                      [type][checksum] of table/block_based_table_builder.cc:626-631.  The image must
                                      be writable there and the trailers must not overlap other buffers. */
 
+#define TCRC_F_SHORT_SPANS 0x10u  /* descriptor lists: most buffers are shorter than about 1.4 KiB.  Results do not
+                                     depend on it; the engine then puts four lanes on a buffer instead of eight
+                                     (sixteen buffers to a wave), which is faster for such buffers and slower for
+                                     longer ones.  Uniform blocks need no hint: their length is known. */
+
 /* verify result block (device memory, 3 x uint64): */
 #define TCRC_CNT_MISMATCH 0  /* number of buffers whose checksum did not match */
 #define TCRC_CNT_FIRST_BAD 1 /* smallest index of a mismatching buffer, ~0 if none */

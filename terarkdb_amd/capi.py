@@ -22,7 +22,7 @@ lib = C.CDLL(LIB_PATH)
 
 OK = 0
 ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_TOO_LARGE = -1, -2, -3, -4
-F_MASK, F_EXPECT_AFTER, F_EXPECT_BEFORE, F_STORE_AFTER = 1, 2, 4, 8
+F_MASK, F_EXPECT_AFTER, F_EXPECT_BEFORE, F_STORE_AFTER, F_SHORT_SPANS = 1, 2, 4, 8, 16
 CNT_MISMATCH, CNT_FIRST_BAD, CNT_CHECKED, CNT_WORDS = 0, 1, 2, 3
 
 

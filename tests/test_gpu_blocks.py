@@ -61,6 +61,21 @@ def test_uniform_other_geometries(eng, blen, stride):
     assert (out.cpu().numpy().view(np.uint32) == want).all()
 
 
+@pytest.mark.parametrize("blen,stride", [(1000, 1003), (1408, 1408), (1409, 1411), (17, 19)])
+def test_many_short_uniform_blocks(eng, blen, stride):
+    """Enough short blocks that the engine puts four lanes on each (up to 1408 bytes), and just above that."""
+    import gpu_util as G
+    n = 40000
+    host = O.splitmix(((n * stride + 64) // 8) * 8, 23)
+    dev = G.to_dev(host)
+    out = torch.zeros(n, dtype=torch.int32, device="cuda")
+    eng.blocks_stamp(dev, n, blen, stride, out, init=0, suffix_byte=3, flags=1)
+    torch.cuda.synchronize()
+    offs = np.arange(n, dtype=np.uint64) * stride
+    want = O.batch_extend(host, offs, np.full(n, blen, np.uint32), np.zeros(n, np.uint32), np.full(n, 3, np.uint8), True)
+    assert (out.cpu().numpy().view(np.uint32) == want).all()
+
+
 def test_descriptor_batch_ragged(eng):
     import gpu_util as G
     import terarkdb_amd.capi as capi
@@ -254,7 +269,7 @@ def test_batch_entry_points_can_be_captured_in_a_graph():
     eng.close()
 
 
-@pytest.mark.parametrize("n", [37, 5000, 20000])  # the engine picks 64, 16 and 8 lanes per buffer for these
+@pytest.mark.parametrize("n", [37, 5000, 20000, 20001])  # the engine picks 64, 16, 8 and (with the hint) 4 lanes per buffer
 def test_randomised_descriptor_batches_with_engine_chosen_geometry(n):
     import gpu_util as G
     import terarkdb_amd.capi as capi
@@ -277,8 +292,9 @@ def test_randomised_descriptor_batches_with_engine_chosen_geometry(n):
         masked = bool(seed & 1)
         desc = capi.make_desc_tensor(offs, lens, inits, "cuda")
         out = torch.zeros(n, dtype=torch.int32, device="cuda")
+        hint = capi.F_SHORT_SPANS if n == 20001 else 0  # results must not depend on the hint
         eng.batch_stamp(dev, desc, n, out, suffix=None if sfx is None else G.to_dev(sfx),
-                        flags=capi.F_MASK if masked else 0)
+                        flags=(capi.F_MASK if masked else 0) | hint)
         torch.cuda.synchronize()
         want = O.batch_extend(host, offs, lens, inits, sfx, masked)
         got = out.cpu().numpy().view(np.uint32)

@@ -14,7 +14,8 @@ for L, stride in ((2046, 2053), (4090, 4101), (1000, 1003)):
     offs = np.arange(n, dtype=np.uint64) * stride
     desc = capi.make_desc_tensor(offs, np.full(n, L, np.uint32), np.zeros(n, np.uint32), "cuda")
     out = torch.zeros(n, dtype=torch.int32, device="cuda")
-    fn = lambda: eng.batch_stamp(data, desc, n, out, flags=capi.F_MASK)
+    hint = capi.F_SHORT_SPANS if os.environ.get('EXP_SHORT_HINT') and L < 1400 else 0
+    fn = lambda: eng.batch_stamp(data, desc, n, out, flags=capi.F_MASK | hint)
     t_end = time.perf_counter() + 1.5
     while time.perf_counter() < t_end:
         for _ in range(20): fn()
