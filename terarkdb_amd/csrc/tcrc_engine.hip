@@ -1217,11 +1217,15 @@ int run_segments(tcrc_ctx* ctx, BatchParams p, const LongArgs& la, void* stream)
   p.flags = kFlagSegments;
   p.uniform_suffix = -1;
   const uint64_t rounds = (p.n + (64 / G) - 1) / (64 / G);
-  // A small launch spreads over 64 workgroups first (a CU alone pulls its bytes slowly), then fills their
-  // sixteen waves, then takes more workgroups: every workgroup ends with one arrival at an accumulator line,
-  // and arrivals at one line queue (about 20 ns each).
+  // A small launch spreads over 64 workgroups first (a CU alone pulls its bytes slowly), then gives each of
+  // them up to eight waves of work, then takes more workgroups, and only with every CU busy goes on to
+  // sixteen waves: every workgroup ends with one arrival at an accumulator line, and arrivals at one line
+  // queue (about 20 ns each); sixteen waves of a few rows each on one CU cost more (every segment has some
+  // 700 instructions of edge work) than the same rows on two CUs (16 MiB in one buffer: 26.5 us with sixteen
+  // waves first, 23.7 us with eight).
+  constexpr uint64_t kSegFill = 8;
   uint64_t wgs64 = rounds < 64 ? rounds : 64;
-  const uint64_t filled = (rounds + kWavesPerWg - 1) / kWavesPerWg;
+  const uint64_t filled = (rounds + kSegFill - 1) / kSegFill;
   if (filled > wgs64) wgs64 = filled;
   const unsigned wgs = (unsigned)(wgs64 < (uint64_t)ctx->cus ? wgs64 : (uint64_t)ctx->cus);
   ctx->st_batch_launches.fetch_add(1, std::memory_order_relaxed);

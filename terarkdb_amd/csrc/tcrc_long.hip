@@ -58,13 +58,17 @@ __global__ __launch_bounds__(1024) void k_pow_tables(uint32_t* tables) {
   }
 }
 
-// Segment length for a call: the shortest power of two from 512 bytes up that leaves every lane group of the
-// chip (8 per wave, 16 waves per CU) at most about one segment - short segments spread a small call over many
-// waves, and what the waves of a workgroup deliver to a buffer is folded in LDS before it reaches the buffer's
-// accumulator line, so the arrivals that queue there number segments / 128.
+// Segment length for a call.  512 bytes up to 2 MiB in all: short segments spread a small call over many waves
+// (what the waves of a workgroup deliver to a buffer is folded in LDS before it reaches the buffer's accumulator
+// line, so the arrivals that queue there number one per workgroup).  Then 1 KiB and 2 KiB, which keep a call of
+// up to 8 MiB within 512 rounds of eight segments - 64 workgroups of eight waves: a segment costs some 700
+// instructions beside its rows, so more and shorter segments than the chip needs to be busy only add work
+// (4 MiB in one buffer: 19.0 us with 512-byte segments, 16.5 us with 1 KiB).  Beyond that the shortest power of
+// two that leaves every lane group of the chip (8 per wave, 16 waves per CU) at most about one segment.
 uint32_t choose_shift(const tcrc_ctx* ctx, uint64_t total) {
   const uint64_t groups = (uint64_t)ctx->cus * 16 * 8;
   uint32_t shift = 9;
+  while (shift < 11 && (total >> shift) > 4096u) ++shift;  // up to 2 KiB while that keeps the launch within 512 rounds
   while (shift < 16 && (total >> shift) > groups) ++shift;
   return shift;
 }
