@@ -307,7 +307,7 @@ int tcrc_host_batch_stamp(tcrc_ctx* ctx, const void* h_base, uint64_t base_bytes
   if (wants_long_route(h_desc, n, h_suffix)) {
     if (int rc = check_flags_host(flags, TCRC_F_MASK)) return rc;
     if (int rc = long_route(ctx, L, h_base, base_bytes, h_desc, n, h_out)) return rc;
-    guard.dismiss();  // long_route returns with the stream drained
+    guard.dismiss();  // long_route returns with the kernel's results complete: the copies ahead of it have finished
     if (flags & TCRC_F_MASK)
       for (uint64_t i = 0; i < n; ++i) h_out[i] = tcrc_mask(h_out[i]);
     return TCRC_OK;
@@ -403,7 +403,7 @@ int tcrc_host_batch_verify(tcrc_ctx* ctx, const void* h_base, uint64_t base_byte
       return fail(TCRC_ERR_INVALID, "verify needs h_expected or an in-image expectation flag");
     std::vector<uint32_t> crc(n);
     if (int rc = long_route(ctx, L, h_base, base_bytes, h_desc, n, crc.data())) return rc;
-    guard.dismiss();  // long_route returns with the stream drained
+    guard.dismiss();  // long_route returns with the kernel's results complete: the copies ahead of it have finished
     for (uint64_t i = 0; i < n; ++i) {
       const uint32_t masked = tcrc_mask(crc[i]);
       uint32_t stored;
@@ -623,7 +623,7 @@ int tcrc_extend(tcrc_ctx* ctx, uint32_t init, const void* h_data, size_t n, uint
     memcpy(&crc, L->zc + kZcOutOff, 4);
     done += len;
   }
-  guard.dismiss();  // every piece's call returned with the stream drained
+  guard.dismiss();  // every piece's call returned with its result complete: the copy ahead of it has finished
   *out = crc;
   return TCRC_OK;
 }

@@ -229,9 +229,6 @@ struct DeviceScope {
   if (device_scope_.err != hipSuccess)                                                                 \
   return tcrc_internal::fail(TCRC_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(device_scope_.err))
 
-// Synchronises the stream when the scope is left without dismiss(): copies issued from host memory that is
-// about to be freed or reused (a caller's buffer, a local vector, the staging ring) must not stay in flight
-// behind an error return.
 // Waits for the completion word of a launch (DoneSignal); a launch that takes longer than a few hundred
 // microseconds, or that failed and will never write its word, ends in an ordinary stream synchronisation.
 inline hipError_t wait_done(const uint32_t* h_flag, uint32_t value, hipStream_t s) {
@@ -245,6 +242,9 @@ inline hipError_t wait_done(const uint32_t* h_flag, uint32_t value, hipStream_t 
   }
 }
 
+// Synchronises the stream when the scope is left without dismiss(): copies issued from host memory that is
+// about to be freed or reused (a caller's buffer, a local vector, the staging ring) must not stay in flight
+// behind an error return.
 struct StreamGuard {
   hipStream_t s;
   bool armed = true;
