@@ -96,9 +96,8 @@ __device__ __forceinline__ uint32_t fold_aux(const uint32_t* t, uint32_t c) {
 // The remainder of one span per lane group: bytes [ptr, ptr + len) fed to the register ~init.  Returns the
 // register BEFORE the final inversion (and before any suffix byte), meaningful on the last lane of every
 // group whose `valid` is set; groups that are not valid walk nothing.  All 64 lanes of the wave must call it
-// together (the row count is agreed on with shuffles).  keep_tail: load the burst that holds the last row
-// with the default cache policy (something is about to be stored right behind the span).  safe: 4 KiB of
-// readable global memory that lane groups without rows load from where the others load rows.
+// together (the row count is agreed on with shuffles).  safe: 4 KiB of readable global memory that lane
+// groups without rows load from where the others load rows.
 // reduction sets, then x^(-8t) * x^(32 l / UL) for t < D, l < UL
 template <int G> struct AuxDwords {
   static constexpr int value = (1 + Geo<G>::kLog2) * 1024 + 16 * G * (G <= 16 ? 4 : 1);
@@ -106,8 +105,7 @@ template <int G> struct AuxDwords {
 
 template <int G, bool NT>
 __device__ __forceinline__ uint32_t span_remainder(const uint32_t* lds, uint32_t LB, int lane, const uint8_t* ptr,
-                                                   uint32_t len, uint32_t init, bool valid, bool keep_tail,
-                                                   const uint8_t* safe) {
+                                                   uint32_t len, uint32_t init, bool valid, const uint8_t* safe) {
   constexpr int D = 16 * G;
   constexpr int LOG2G = Geo<G>::kLog2;
   // lanes of a group that share the un-shift multiplication (a whole wave per buffer keeps it on one lane:
@@ -149,10 +147,13 @@ __device__ __forceinline__ uint32_t span_remainder(const uint32_t* lds, uint32_t
   };
   // A column that may stick out of the message at either end or hold some of its first four
   // bytes (which carry the initial register): loaded only if it overlaps the message ...
-  auto load_checked = [&](uint32_t r, bool keep) -> uint4 {
+  auto load_checked = [&](uint32_t r) -> uint4 {
     const int m = m0 + (int)(r * D);
     uint4 v = make_uint4(0u, 0u, 0u, 0u);
-    if (live && m > -16 && m < (int)elen) v = (NT && !keep) ? load16<true>(ptr + m) : load16<false>(ptr + m);
+    // default cache policy, not the streaming one of the whole rows: the line a span starts or ends in is
+    // usually also the line its neighbour ends or starts in, and is wanted again within microseconds
+    // (4 KiB blocks packed end to end: 6.7 TB/s against 6.2 with streaming loads here too)
+    if (live && m > -16 && m < (int)elen) v = load16<false>(ptr + m);
     return v;
   };
   // ... and trimmed to the message, with the initial register folded into message bytes 0..3.
@@ -252,14 +253,10 @@ __device__ __forceinline__ uint32_t span_remainder(const uint32_t* lds, uint32_t
     auto bursts = [&](uint32_t from, uint32_t to) {
       for (uint32_t x = from; x < to; x += 4u) {
         const uint32_t cnt = to - x;  // rows in this burst if fewer than four
-        // When the trailer is stored into the image behind the buffer, the burst that holds the last row
-        // is loaded with the default cache policy: the line the store goes to is then still in the cache,
-        // and the store does not have to fetch it again.
-        const bool keep = keep_tail && x + 4u >= Rmax;
-        const uint4 a = load_checked(x, keep);
-        const uint4 b = cnt > 1u ? load_checked(x + 1u, keep) : z;
-        const uint4 c = cnt > 2u ? load_checked(x + 2u, keep) : z;
-        const uint4 d = cnt > 3u ? load_checked(x + 3u, keep) : z;
+        const uint4 a = load_checked(x);
+        const uint4 b = cnt > 1u ? load_checked(x + 1u) : z;
+        const uint4 c = cnt > 2u ? load_checked(x + 2u) : z;
+        const uint4 d = cnt > 3u ? load_checked(x + 3u) : z;
         if (x >= head_end && x < tail_begin) fold_plain(a); else fold_checked(a, x);
         if (cnt > 1u) {
           if (x + 1u >= head_end && x + 1u < tail_begin) fold_plain(b); else fold_checked(b, x + 1u);
@@ -472,6 +469,39 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p, typename 
     round_first = (uint64_t)(tid >> 6) < wpw ? w * k : nrounds;
     round_last = round_first + k < nrounds ? round_first + k : nrounds;
   }
+  // Results stored into the image (a trailer behind its block, TCRC_F_STORE_AFTER; a checksum into the record
+  // header in front of its span) are kept back: lane i of a group holds the result of the group's i-th round
+  // since the last flush, and after G rounds - or at the end - every lane stores one of them.  Five-byte stores
+  // between the row loads of the next round cost 4 KiB blocks a tenth of their rate (5.9 TB/s against 6.7 for
+  // results that go to an array); in bursts of G rounds, behind the wave's last load, a third of that (6.4 TB/s).
+  const bool defer = !SEG && (p.flags & (TCRC_F_STORE_AFTER | kFlagStampBefore)) != 0;
+  uint32_t pend_result = 0, pend_rounds = 0;
+  uint64_t pend_first = 0;
+  auto flush_trailers = [&]() {
+    const uint64_t buf = (pend_first + (uint64_t)j * round_step) * GPW + grp;
+    if ((uint32_t)j < pend_rounds && buf < n) {
+      uint64_t off = buf * p.stride;
+      uint32_t len = p.block_len;
+      if (p.desc) {
+        const tcrc_desc dsc = p.desc[buf];
+        off = dsc.offset;
+        len = dsc.len > kMaxSpan ? 0u : dsc.len;
+      }
+      if (p.flags & TCRC_F_STORE_AFTER) {
+        int sfx = p.uniform_suffix;
+        if (p.suffix) sfx = p.suffix[buf];
+        uint8_t* t = const_cast<uint8_t*>(p.base) + off + len;
+        if (sfx >= 0) *t++ = (uint8_t)sfx;
+        __builtin_memcpy(t, &pend_result, 4);
+      }
+      if ((p.flags & kFlagStampBefore) && len != 0u) {
+        // into the record header of a log image being framed (the image is writable there)
+        uint8_t* h = const_cast<uint8_t*>(p.base) + off - 6;
+        __builtin_memcpy(h, &pend_result, 4);
+      }
+    }
+    pend_rounds = 0;
+  };
   for (uint64_t round = round_first; round < round_last; round += round_step) {
     const uint64_t buf = round * GPW + grp;
     const bool valid = buf < n;
@@ -547,10 +577,9 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p, typename 
       }
     }
     const uint8_t* ptr = p.base + off;
-    const uint32_t core = span_remainder<G, NT>(lds, LB, lane, ptr, len, init, valid,
-                                                (p.flags & TCRC_F_STORE_AFTER) != 0, (const uint8_t*)p.tab_main);
+    const uint32_t core = span_remainder<G, NT>(lds, LB, lane, ptr, len, init, valid, (const uint8_t*)p.tab_main);
 
-    uint32_t seg_value = 0;
+    uint32_t seg_value = 0, round_result = 0;
     bool seg_have = false;
     if (valid && j == G - 1) {
       uint32_t reg = core;
@@ -571,16 +600,7 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p, typename 
       } else {
         const uint32_t result = (p.flags & TCRC_F_MASK) ? masked : crc;
         if (p.out) p.out[buf] = result;
-        if (p.flags & TCRC_F_STORE_AFTER) {
-          uint8_t* t = const_cast<uint8_t*>(p.base) + off + len;
-          if (sfx >= 0) *t++ = (uint8_t)sfx;
-          __builtin_memcpy(t, &result, 4);
-        }
-        if ((p.flags & kFlagStampBefore) && len != 0u) {
-          // into the record header of a log image being framed (the image is writable there)
-          uint8_t* h = const_cast<uint8_t*>(p.base) + off - 6;
-          __builtin_memcpy(h, &result, 4);
-        }
+        round_result = result;
       }
       if (p.verify) {
         const bool good = stored == masked && !oversize;
@@ -590,6 +610,12 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p, typename 
           atomicMin(&p.counts[TCRC_CNT_FIRST_BAD], (unsigned long long)buf);
         }
       }
+    }
+    if (defer) {
+      const uint32_t r = __shfl(round_result, lane | (G - 1));
+      if ((uint32_t)j == pend_rounds) pend_result = r;
+      if (pend_rounds == 0u) pend_first = round;
+      if (++pend_rounds == (uint32_t)G) flush_trailers();
     }
     if constexpr (SEG) {
       // The segments of one wave usually belong to one buffer: fold them with shuffles and touch the
@@ -621,6 +647,7 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p, typename 
       }
     }
   }
+  if (defer && pend_rounds) flush_trailers();
   if (p.verify && blockIdx.x == 0 && tid == 0) atomicAdd(&p.counts[TCRC_CNT_CHECKED], (unsigned long long)n);
   if constexpr (SEG) {
     // What the waves still hold meets in LDS: when it is all for one buffer (the usual case) the workgroup
@@ -1018,7 +1045,7 @@ __global__ __launch_bounds__(kThreads) void k_wal_fused(WalScanParams p) {
     // the stored value is fetched now so its latency hides behind the row loop
     uint32_t stored = 0;
     if (valid && first && j == G - 1) __builtin_memcpy(&stored, ptr - 6, 4);
-    const uint32_t core = span_remainder<G, NT>(lds, LB, lane, ptr, len, first ? 0u : 0xffffffffu, valid, false,
+    const uint32_t core = span_remainder<G, NT>(lds, LB, lane, ptr, len, first ? 0u : 0xffffffffu, valid,
                                                 (const uint8_t*)p.tab_main);
     // A piece with q pieces behind it enters its span's remainder multiplied by x^(8 * kWalPiece * q).  The 32
     // shift-and-xor steps of that multiplication are split over four lanes of the group, like the un-shift in

@@ -227,6 +227,48 @@ def test_trailers_stored_in_place(eng):
         eng.batch_stamp(dev2, desc, 300, out, flags=0x100)
 
 
+def test_trailers_stored_in_place_over_many_rounds_per_wave(eng):
+    """In-place trailers are held back and stored in bursts, one per lane of a group; with more rounds per wave
+    than a group has lanes there are bursts inside the loop and a partial one at its end.  Whole images against
+    the oracle: uniform short blocks (four lanes per block, sixteen blocks per wave round) and a packed
+    descriptor list with per-block type bytes (eight lanes per span)."""
+    import gpu_util as G
+    import terarkdb_amd.capi as capi
+    # 4096 waves x 16 blocks per round x (4 lanes + 1) rounds, and some
+    n, blen, stride = 4096 * 16 * 5 + 777, 96, 101
+    host = O.splitmix((n * stride + 7) // 8 * 8, 93).copy()
+    dev = G.to_dev(host)
+    eng.blocks_stamp(dev, n, blen, stride, None, suffix_byte=2, flags=capi.F_MASK | capi.F_STORE_AFTER)
+    torch.cuda.synchronize()
+    want_img = host.copy()
+    rows = want_img[:n * stride].reshape(n, stride)
+    rows[:, blen] = 2
+    rows[:, blen + 1:blen + 5] = O.sst_trailer_batch(host, blen, stride, n, 2).astype("<u4").view(np.uint8).reshape(n, 4)
+    assert (dev.cpu().numpy() == want_img).all()
+    # 4096 waves x 8 spans per round x (8 lanes + 3) rounds, and some
+    rng = np.random.default_rng(13)
+    m = 4096 * 8 * 11 + 123
+    lens = rng.integers(130, 260, m).astype(np.uint32)
+    types = rng.integers(0, 8, m).astype(np.uint8)
+    offs = np.concatenate([[0], np.cumsum(lens.astype(np.uint64) + 5)[:-1]]).astype(np.uint64)
+    total = int(offs[-1] + lens[-1] + 5)
+    host2 = O.splitmix((total + 7) // 8 * 8, 94).copy()
+    dev2 = G.to_dev(host2)
+    desc = capi.make_desc_tensor(offs, lens, np.zeros(m, np.uint32), "cuda")
+    out = torch.zeros(m, dtype=torch.int32, device="cuda")
+    eng.batch_stamp(dev2, desc, m, out, suffix=G.to_dev(types), flags=capi.F_MASK | capi.F_STORE_AFTER)
+    torch.cuda.synchronize()
+    want = O.batch_extend(host2, offs, lens, None, types, True)
+    assert (out.cpu().numpy().view(np.uint32) == want).all()
+    want_img2 = host2.copy()
+    at = (offs + lens).astype(np.int64)
+    want_img2[at] = types
+    wb = want.astype("<u4").view(np.uint8).reshape(m, 4)
+    for k in range(4):
+        want_img2[at + 1 + k] = wb[:, k]
+    assert (dev2.cpu().numpy() == want_img2).all()
+
+
 def test_batch_entry_points_can_be_captured_in_a_graph():
     """The batch entry points only enqueue kernels (no allocation, no synchronisation), so a caller with a
     launch-bound loop can record them into a HIP graph and replay it."""

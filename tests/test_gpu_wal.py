@@ -228,6 +228,28 @@ def test_device_framing_is_byte_identical_to_the_cpu_writer(recycle):
     eng.close()
 
 
+def test_device_framing_of_many_small_records():
+    """More physical records than one round per lane of every wave's groups (4096 waves x 8 groups x 8 lanes):
+    the header checksums are stored in bursts inside the stamp kernel's loop and once more at its end."""
+    import gpu_util as G
+    import terarkdb_amd.capi as capi
+    eng = G.engine()
+    rng = np.random.default_rng(5)
+    n = 4096 * 8 * 9 + 321
+    lens = rng.integers(0, 120, n).astype(np.uint32)
+    offs = np.concatenate([[0], np.cumsum(lens.astype(np.uint64))[:-1]]).astype(np.uint64) + 3
+    src = O.splitmix((int(lens.sum()) + 64 + 7) // 8 * 8, 78)
+    records = [src[int(o):int(o) + int(ln)].tobytes() for o, ln in zip(offs, lens)]
+    want, _ = _oracle_image(records, False, 9)
+    dst = torch.full((len(want) + 64,), 0xCD, dtype=torch.uint8, device="cuda")
+    written, bo, phys = eng.wal_frame(G.to_dev(src), offs.tolist(), lens.tolist(), 9, False, dst)
+    torch.cuda.synchronize()
+    got = dst.cpu().numpy()
+    assert written == len(want) and bo == len(want) % 32768 and phys >= n
+    assert got[:written].tobytes() == want and (got[written:] == 0xCD).all()
+    eng.close()
+
+
 def test_scan_of_garbage_and_preallocated_images_matches_oracle():
     """Images that are not logs at all: random bytes, zeros (a preallocated file), a valid log followed by
     zeros and by random bytes, odd sizes.  The structural walk must end every block where the CPU rules do."""

@@ -31,6 +31,8 @@ variants = [
     ("stamp to an array, type bytes from an array", lambda: eng.batch_stamp(image, d_len, nblk, out, suffix=types, flags=M)),
     ("stamp in place (4 bytes), type byte inside the span", lambda: eng.batch_stamp(image, d_len1, nblk, None, flags=M | SA)),
     ("stamp in place (type + 4 bytes), type bytes from an array", lambda: eng.batch_stamp(image, d_len, nblk, None, suffix=types, flags=M | SA)),
+    ("stamp in place AND to an array, type byte inside the span", lambda: eng.batch_stamp(image, d_len1, nblk, out, flags=M | SA)),
+    ("stamp in place AND to an array, type bytes from an array", lambda: eng.batch_stamp(image, d_len, nblk, out, suffix=types, flags=M | SA)),
 ]
 for rep in range(2):
     for name, fn in variants:
