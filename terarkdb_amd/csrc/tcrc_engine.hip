@@ -363,8 +363,12 @@ __device__ __forceinline__ void fill_main_tables(uint32_t* lds, const uint32_t* 
   }
 }
 
-template <bool SEG> struct SegArgs { typedef NoLongArgs type; };
-template <> struct SegArgs<true> { typedef LongArgs type; };
+// What a batch launch does with its results besides writing them to arrays.
+constexpr int kModePlain = 0;     // nothing
+constexpr int kModeSegments = 1;  // the items are segments of long buffers: results are shifted and folded per buffer
+constexpr int kModeInImage = 2;   // results are also stored into the image (TCRC_F_STORE_AFTER, kFlagStampBefore)
+template <int MODE> struct SegArgs { typedef NoLongArgs type; };
+template <> struct SegArgs<kModeSegments> { typedef LongArgs type; };
 
 // One segment's remainder enters its buffer's accumulator line: XOR, then the arrival count; whoever
 // completes the count takes the value out, leaves the line zeroed for the next launch and writes the result.
@@ -398,9 +402,12 @@ __device__ __forceinline__ void seg_arrive(uint32_t* line, uint32_t value, uint3
   }
 }
 
-// SEG: the items are segments of long buffers described by `la` (tcrc_long.hip); otherwise `la` is empty.
-template <int G, bool NT, bool SEG>
-__global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p, typename SegArgs<SEG>::type la) {
+// kModeSegments: the items are segments of long buffers described by `la` (tcrc_long.hip); otherwise `la` is
+// empty.  The modes are separate instantiations so that what one needs (registers, above all) costs the others
+// nothing: the plain one is the benchmark's.
+template <int G, bool NT, int MODE>
+__global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p, typename SegArgs<MODE>::type la) {
+  constexpr bool SEG = MODE == kModeSegments;
   constexpr int GPW = 64 / G;  // groups (buffers) per wave
   constexpr int kAuxDwords = AuxDwords<G>::value;
   __shared__ __align__(16) uint32_t lds[kMainDwords + kAuxDwords];
@@ -474,7 +481,7 @@ __global__ __launch_bounds__(kThreads) void k_crc_batch(BatchParams p, typename 
   // since the last flush, and after G rounds - or at the end - every lane stores one of them.  Five-byte stores
   // between the row loads of the next round cost 4 KiB blocks a tenth of their rate (5.9 TB/s against 6.7 for
   // results that go to an array); in bursts of G rounds, behind the wave's last load, a third of that (6.4 TB/s).
-  const bool defer = !SEG && (p.flags & (TCRC_F_STORE_AFTER | kFlagStampBefore)) != 0;
+  constexpr bool defer = MODE == kModeInImage;
   uint32_t pend_result = 0, pend_rounds = 0;
   uint64_t pend_first = 0;
   auto flush_trailers = [&]() {
@@ -1165,10 +1172,18 @@ int launch_batch(tcrc_ctx* ctx, BatchParams p, hipStream_t s) {
   uint64_t wgs = rounds;
   if (wgs > (uint64_t)ctx->cus) wgs = (uint64_t)ctx->cus;
   if (wgs == 0) wgs = 1;
-  if (ctx->nontemporal)
-    hipLaunchKernelGGL((k_crc_batch<G, true, false>), dim3((unsigned)wgs), dim3(kThreads), 0, s, p, NoLongArgs{});
-  else
-    hipLaunchKernelGGL((k_crc_batch<G, false, false>), dim3((unsigned)wgs), dim3(kThreads), 0, s, p, NoLongArgs{});
+  const bool in_image = (p.flags & (TCRC_F_STORE_AFTER | kFlagStampBefore)) != 0;
+  if (ctx->nontemporal) {
+    if (in_image)
+      hipLaunchKernelGGL((k_crc_batch<G, true, kModeInImage>), dim3((unsigned)wgs), dim3(kThreads), 0, s, p, NoLongArgs{});
+    else
+      hipLaunchKernelGGL((k_crc_batch<G, true, kModePlain>), dim3((unsigned)wgs), dim3(kThreads), 0, s, p, NoLongArgs{});
+  } else {
+    if (in_image)
+      hipLaunchKernelGGL((k_crc_batch<G, false, kModeInImage>), dim3((unsigned)wgs), dim3(kThreads), 0, s, p, NoLongArgs{});
+    else
+      hipLaunchKernelGGL((k_crc_batch<G, false, kModePlain>), dim3((unsigned)wgs), dim3(kThreads), 0, s, p, NoLongArgs{});
+  }
   HIP_TRY(hipGetLastError());
   return TCRC_OK;
 }
@@ -1259,9 +1274,9 @@ int run_segments(tcrc_ctx* ctx, BatchParams p, const LongArgs& la, void* stream)
   ctx->st_batch_buffers.fetch_add(p.n, std::memory_order_relaxed);
   hipStream_t s = (hipStream_t)stream;
   if (ctx->nontemporal)
-    hipLaunchKernelGGL((k_crc_batch<G, true, true>), dim3(wgs), dim3(kThreads), 0, s, p, la);
+    hipLaunchKernelGGL((k_crc_batch<G, true, kModeSegments>), dim3(wgs), dim3(kThreads), 0, s, p, la);
   else
-    hipLaunchKernelGGL((k_crc_batch<G, false, true>), dim3(wgs), dim3(kThreads), 0, s, p, la);
+    hipLaunchKernelGGL((k_crc_batch<G, false, kModeSegments>), dim3(wgs), dim3(kThreads), 0, s, p, la);
   HIP_TRY(hipGetLastError());
   return TCRC_OK;
 }

@@ -16,9 +16,9 @@ with tempfile.TemporaryDirectory() as d:
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", SRC,
                            "-o", os.path.join(d, "e.o"), "--save-temps"], cwd=d, stderr=subprocess.DEVNULL)
     asm = open(os.path.join(d, "tcrc_engine-hip-amdgcn-amd-amdhsa-gfx950.s")).read().split("\n")
-want = {"k_crc_batchILi8ELb1ELb0E": "k_crc_batch<8 lanes, non-temporal> (headline kernel)",
-        "k_crc_batchILi4ELb1ELb0E": "k_crc_batch<4 lanes, non-temporal>",
-        "k_crc_batchILi8ELb1ELb1E": "k_crc_batch<8 lanes, non-temporal, segments> (long buffers)",
+want = {"k_crc_batchILi8ELb1ELi0E": "k_crc_batch<8 lanes, non-temporal> (headline kernel)",
+        "k_crc_batchILi4ELb1ELi0E": "k_crc_batch<4 lanes, non-temporal>",
+        "k_crc_batchILi8ELb1ELi1E": "k_crc_batch<8 lanes, non-temporal, segments> (long buffers)",
         "k_wal_fusedILb1E": "k_wal_fused<non-temporal> (log scan)"}
 print("# gfx950 ISA of terarkdb_amd/csrc/tcrc_engine.hip: blocks with at least 16 ds_read_b32 (the row folds)")
 print("# a row fold of one lane = one 16-byte load, 16 lookups (4 per dword): 4 x (4 v_perm_b32 + 4 v_xor_b32) = 32 VALU")
