@@ -274,8 +274,7 @@ __device__ __forceinline__ uint32_t span_remainder(const uint32_t* lds, uint32_t
     // to the load of the row four further on, so the memory latency is paid once and not once per four rows
     // (buffers of a few KiB are bound by that latency, not by bandwidth).  That loop has no branch in it -
     // lane groups that walk nothing read a harmless address instead of being masked off - because only then
-    // does the compiler count the loads in flight instead of waiting for all of them.  What is left (up to
-    // three whole rows and the last row) is one more checked burst.
+    // does the compiler count the loads in flight instead of waiting for all of them.
     const uint32_t mid_end = head_end + ((tail_begin - head_end) & ~3u);
     bursts(0u, head_end);
     if (mid_end > head_end) {
@@ -301,7 +300,23 @@ __device__ __forceinline__ uint32_t span_remainder(const uint32_t* lds, uint32_t
       fold_plain(c);
       fold_plain(d);
     }
-    bursts(mid_end, Rmax);
+    // What is left is one more burst: the whole rows that did not make a multiple of four (up to three) - as whole
+    // as the others, so plain streaming loads counted with scalar instructions - and behind them, in flight
+    // together with them, the last row, which alone goes through the checks (a checked row costs some fifty
+    // vector instructions on top of its thirty-two).
+    if (tail_begin + 1u == Rmax) {
+      const uint32_t left = tail_begin - mid_end;
+      const uint8_t* q = live ? ptr + (m0 + (int)(mid_end * D)) : safe;
+      const uint32_t qd = live ? (uint32_t)D : 0u;
+      const uint4 a = left > 0u ? load16<NT>(q) : z;
+      const uint4 b = left > 1u ? load16<NT>(q + qd) : z;
+      const uint4 c = left > 2u ? load16<NT>(q + 2u * qd) : z;
+      const uint4 d = load_checked(tail_begin);
+      if (left > 0u) fold_plain(a);
+      if (left > 1u) fold_plain(b);
+      if (left > 2u) fold_plain(c);
+      fold_checked(d, tail_begin);
+    }
   }
 
   // Column states -> one value per lane (bytes j*16 .. j*16+15 of the last row).
