@@ -142,3 +142,28 @@ def test_eight_threads_share_one_context_through_host_calls():
     assert len(done) == 8 and 2 <= lanes <= 16
     print(f"\none thread {one / t_one / 1e9:.2f} GB/s, eight threads on one context {sum(done) / t_eight / 1e9:.2f} GB/s "
           f"({lanes} lanes)")
+
+
+def test_two_contexts_on_one_gpu_run_side_by_side():
+    """Two contexts on the same GPU (two column families' flush threads that were each given an engine of their
+    own): their launches want the same compute units and take turns, and each keeps its own results."""
+    import gpu_util as G
+    engines = [G.engine(), G.engine()]
+    errors, done = [], []
+
+    def worker(t):
+        try:
+            done.append(_host_mix(engines[t % 2], t, 25, True))
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    lanes = [e.stats()["host_lanes"] for e in engines]
+    for e in engines:
+        e.close()
+    assert not errors, errors
+    assert len(done) == 4 and all(1 <= n <= 2 for n in lanes), lanes
