@@ -231,7 +231,7 @@ class Engine:
 
     def extend_long(self, base, offsets, lens, inits, out, segment_len=0, stream=None, noalloc=False):
         """Host descriptor arrays, device data; out is a device int32/uint32 tensor of len(offsets).
-        noalloc=True takes the entry point that allocates nothing (at most 16 buffers; only enqueues)."""
+        noalloc=True takes the entry point that allocates nothing (at most 64 buffers; only enqueues)."""
         n = len(offsets)
         arr = (Desc * max(n, 1))()
         for i in range(n):

@@ -1,0 +1,203 @@
+"""Development aid: randomised parity soak of the device entry points against the CPU checker, for a time
+budget.  Every case draws its own shape from the case number, so a failure names the case to replay:
+
+    python tools/soak.py SECONDS [FIRST_CASE]
+
+Cases rotate over: log scans (size distributions from tiny records to whole-block fragments and the skewed
+mix, both header kinds, clean and damaged, whole and truncated images), descriptor batches (any offset, any
+length, initial values, suffix bytes, masked or not, in-image expectations), uniform blocks, and long buffers
+(both entry points, random segment lengths).  Prints a progress line every few seconds; exits non-zero at the
+first difference."""
+import os, sys, time
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_lib as O
+import terarkdb_amd.capi as capi
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+case = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+eng = capi.Engine(0)
+FILL = O.splitmix(1 << 20, 11).tobytes()
+done = {"log": 0, "batch": 0, "blocks": 0, "long": 0}
+
+
+def log_sizes(kind, rng, total):
+    out, acc = [], 0
+    while acc < total:
+        if kind == 0:
+            n = int(rng.integers(0, 64))
+        elif kind == 1:
+            n = int(rng.integers(0, 1200))
+        elif kind == 2:
+            n = int(rng.choice([2040, 2041, 2042, 2047, 2048, 2049, 4089, 4090, 4096, 4097, 6137, 6138, 32761, 32762]))
+        elif kind == 3:
+            n = int(rng.integers(1, 1 << int(rng.integers(1, 18))))  # the reference test's skewed shape
+        elif kind == 4:
+            n = int(rng.integers(100000, 400000))
+        else:
+            n = int(rng.choice([0, 1, 5, 30000, 32761, 32768, 70000])) if rng.random() < 0.5 else int(rng.integers(0, 64))
+        out.append(n)
+        acc += n + 7
+    return out
+
+
+def case_log(c, rng):
+    recycle = bool(rng.integers(0, 2))
+    kind = int(rng.integers(0, 6))
+    total = int(rng.integers(1, 1 << int(rng.integers(12, 26))))
+    if kind == 0:
+        total = min(total, 4 << 20)
+    lognum = int(rng.integers(1, 1 << 20))
+    t = O.OracleLog(recycle=recycle, log_number=lognum)
+    for n in log_sizes(kind, rng, total):
+        o = int(rng.integers(0, len(FILL) - n)) if n < len(FILL) else 0
+        t.write(FILL[o:o + n])
+    img = np.frombuffer(t.contents(), dtype=np.uint8).copy()
+    t.close()
+    mode = int(rng.integers(0, 4))
+    if mode == 1 and img.size > 10:  # cut somewhere
+        img = img[:int(rng.integers(1, img.size))].copy()
+    if mode >= 2:  # damage
+        for pos in rng.integers(0, img.size, int(rng.integers(1, 200))):
+            img[int(pos)] ^= 1 << int(rng.integers(0, 8))
+    if img.size == 0:
+        return
+    nb = (img.size + 32767) // 32768
+    want = np.zeros((nb, 4), dtype=np.uint32)
+    O.lib().oracle_wal_scan_blocks(img.ctypes.data, img.size, lognum, want.ctypes.data)
+    dev = torch.from_numpy(img).cuda()
+    blocks = torch.zeros((nb, 4), dtype=torch.int32, device="cuda")
+    counts = torch.zeros(capi.CNT_WORDS, dtype=torch.int64, device="cuda")
+    eng.counts_reset(counts)
+    n = eng.wal_verify(dev, img.size, lognum, blocks, counts)
+    torch.cuda.synchronize()
+    got = blocks.cpu().numpy().view(np.uint32)
+    cn = counts.cpu().numpy().view(np.uint64)
+    bad = np.nonzero((got != want).any(axis=1))[0]
+    assert bad.size == 0, ("log", c, kind, recycle, mode, img.size, bad[:5], got[bad[:5]], want[bad[:5]])
+    assert n == int(want[:, 0].sum()), ("log records", c, n, int(want[:, 0].sum()))
+    assert int(cn[capi.CNT_MISMATCH]) < (1 << 40), ("log scan gave up waiting", c)
+    firsts = np.nonzero(want[:, 1] != 0xffffffff)[0]
+    if firsts.size:
+        assert int(cn[capi.CNT_FIRST_BAD]) == int(firsts[0]), ("first bad", c)
+    else:
+        assert int(cn[capi.CNT_MISMATCH]) == 0, ("mismatch on a clean image", c)
+    done["log"] += 1
+
+
+def case_batch(c, rng):
+    size = int(rng.integers(64, 1 << int(rng.integers(8, 25)))) & ~7
+    host = O.splitmix(max(size, 64), int(rng.integers(1, 1000)))
+    n = int(rng.integers(1, 1 << int(rng.integers(1, 15))))
+    maxlen = int(rng.choice([16, 130, 1000, 2100, 5000, 20000, 300000]))
+    if maxlen > 20000:
+        n = min(n, 512)  # keeps the checker's share of a case within a second
+    lens = np.minimum(rng.integers(0, maxlen + 1, n), host.size - 8).astype(np.uint32)
+    offs = (rng.integers(0, host.size - 8, n) % (host.size - 8 - lens + 1)).astype(np.uint64)
+    inits = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32) if rng.random() < 0.5 else np.zeros(n, np.uint32)
+    suffix = rng.integers(0, 256, n).astype(np.uint8) if rng.random() < 0.5 else None
+    masked = bool(rng.integers(0, 2))
+    flags = (capi.F_MASK if masked else 0) | (capi.F_SHORT_SPANS if (maxlen <= 1000 and rng.random() < 0.5) else 0)
+    want = O.batch_extend(host, offs, lens, inits, suffix, masked)
+    dev = torch.from_numpy(host).cuda()
+    desc = capi.make_desc_tensor(offs, lens, inits, "cuda")
+    dsuf = None if suffix is None else torch.from_numpy(suffix).cuda()
+    out = torch.zeros(n, dtype=torch.int32, device="cuda")
+    eng.batch_stamp(dev, desc, n, out, suffix=dsuf, flags=flags)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().view(np.uint32)
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, ("batch stamp", c, n, maxlen, bad[:5], offs[bad[:5]], lens[bad[:5]])
+    # verify against expectations (stored values are always the masked ones) with a few wrong ones
+    want = O.batch_extend(host, offs, lens, inits, suffix, True)
+    exp = want.copy()
+    wrong = rng.integers(0, n, int(rng.integers(0, 4)))
+    exp[wrong] ^= 0x10
+    counts = torch.zeros(capi.CNT_WORDS, dtype=torch.int64, device="cuda")
+    ok = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    eng.counts_reset(counts)
+    eng.batch_verify(dev, desc, n, counts, expected=torch.from_numpy(exp.view(np.int32)).cuda(), ok=ok, suffix=dsuf,
+                     flags=flags)
+    torch.cuda.synchronize()
+    okh = ok.cpu().numpy()
+    cn = counts.cpu().numpy().view(np.uint64)
+    assert ((okh != 0) == (exp == want)).all(), ("batch verify verdicts", c)
+    nbad = int((exp != want).sum())
+    assert int(cn[capi.CNT_MISMATCH]) == nbad and int(cn[capi.CNT_CHECKED]) == n, ("batch verify counts", c, cn)
+    if nbad:
+        assert int(cn[capi.CNT_FIRST_BAD]) == int(np.nonzero(exp != want)[0][0]), ("batch first bad", c)
+    done["batch"] += 1
+
+
+def case_blocks(c, rng):
+    blen = int(rng.choice([1, 15, 16, 17, 100, 1000, 1408, 1409, 4096, 4101, 8192, 8197, 16384, 33000]))
+    pad = int(rng.choice([0, 0, 5, 1, 64, 123]))
+    stride = blen + pad
+    n = int(rng.integers(1, max(2, min(1 << 15, (48 << 20) // stride))))
+    lead = int(rng.integers(0, 64))
+    host = O.splitmix(((lead + n * stride + 64) + 7) & ~7, int(rng.integers(1, 1000)))
+    tb = int(rng.integers(0, 256)) if rng.random() < 0.7 else -1
+    if tb >= 0:
+        want = O.sst_trailer_batch(host[lead:], blen, stride, n, tb)
+    else:
+        want = O.batch_extend(host, lead + np.arange(n, dtype=np.uint64) * stride, np.full(n, blen, np.uint32), None, None, True)
+    dev = torch.from_numpy(host).cuda()
+    out = torch.zeros(n, dtype=torch.int32, device="cuda")
+    eng.blocks_stamp(dev[lead:], n, blen, stride, out, suffix_byte=tb, flags=capi.F_MASK)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().view(np.uint32)
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, ("blocks", c, blen, stride, n, lead, tb, bad[:5])
+    if pad >= 5 and tb >= 0:
+        # trailers stored in place, then verified in place
+        eng.blocks_stamp(dev[lead:], n, blen, stride, out, suffix_byte=tb, flags=capi.F_MASK | capi.F_STORE_AFTER)
+        counts = torch.zeros(capi.CNT_WORDS, dtype=torch.int64, device="cuda")
+        eng.counts_reset(counts)
+        eng.blocks_verify(dev[lead:], n, blen, stride, counts, suffix_byte=tb, flags=capi.F_EXPECT_AFTER)
+        torch.cuda.synchronize()
+        img = dev.cpu().numpy()
+        tr = np.stack([img[lead + np.arange(n) * stride + blen + 1 + k] for k in range(4)], axis=1).astype(np.uint32)
+        stored = tr[:, 0] | (tr[:, 1] << 8) | (tr[:, 2] << 16) | (tr[:, 3] << 24)
+        assert (stored == want).all(), ("blocks stored trailers", c, blen, stride)
+        assert (img[lead + np.arange(n) * stride + blen] == tb).all(), ("blocks stored type byte", c)
+        cn = counts.cpu().numpy().view(np.uint64)
+        assert int(cn[capi.CNT_MISMATCH]) == 0 and int(cn[capi.CNT_CHECKED]) == n, ("blocks verify in place", c, cn)
+    done["blocks"] += 1
+
+
+def case_long(c, rng):
+    n = int(rng.choice([1, 1, 2, 7, 16, 64, 65, 300]))
+    maxlen = int(rng.choice([1000, 100000, 1 << 20, 5 << 20, 40 << 20]))
+    if n > 16:
+        maxlen = min(maxlen, 1 << 20)
+    size = min(96 << 20, max(4096, maxlen * min(n, 4)))
+    host = O.splitmix(size & ~7, int(rng.integers(1, 1000)))
+    lens = np.minimum(rng.integers(0, maxlen + 1, n), host.size - 1).astype(np.uint32)
+    offs = (rng.integers(0, host.size, n) % (host.size - lens + 1)).astype(np.uint64)
+    inits = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    seg = int(rng.choice([0, 0, 256, 512, 1024, 4096, 65536, 1 << 20]))
+    noalloc = n <= 64 and rng.random() < 0.5
+    want = O.batch_extend(host, offs, lens, inits, None, False)
+    dev = torch.from_numpy(host).cuda()
+    out = torch.zeros(n, dtype=torch.int32, device="cuda")
+    eng.extend_long(dev, offs.tolist(), lens.tolist(), inits.tolist(), out, segment_len=seg, noalloc=noalloc)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().view(np.uint32)
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, ("long", c, n, seg, noalloc, bad[:5], offs[bad[:5]], lens[bad[:5]])
+    done["long"] += 1
+
+
+CASES = [case_log, case_batch, case_log, case_blocks, case_log, case_long]
+t_end = time.perf_counter() + budget
+t_print = time.perf_counter() + 5
+while time.perf_counter() < t_end:
+    rng = np.random.default_rng(1000003 * case + 17)
+    CASES[case % len(CASES)](case, rng)
+    case += 1
+    if time.perf_counter() > t_print:
+        print(f"case {case}: {done}", flush=True)
+        t_print = time.perf_counter() + 5
+print(f"soak clean: next case {case}; {done}", flush=True)
+eng.close()
