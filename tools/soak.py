@@ -6,7 +6,8 @@ budget.  Every case draws its own shape from the case number, so a failure names
 Cases rotate over: log scans (size distributions from tiny records to whole-block fragments and the skewed
 mix, both header kinds, clean and damaged, whole and truncated images), descriptor batches (any offset, any
 length, initial values, suffix bytes, masked or not, in-image expectations), uniform blocks, and long buffers
-(both entry points, random segment lengths).  Prints a progress line every few seconds; exits non-zero at the
+(both entry points, random segment lengths), and the host-pointer entry points with sizes around the points
+where the engine changes route.  Prints a progress line every few seconds; exits non-zero at the
 first difference."""
 import os, sys, time
 import numpy as np, torch
@@ -19,7 +20,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 case = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 eng = capi.Engine(0)
 FILL = O.splitmix(1 << 20, 11).tobytes()
-done = {"log": 0, "batch": 0, "blocks": 0, "long": 0}
+done = {"log": 0, "batch": 0, "blocks": 0, "long": 0, "host": 0}
 
 
 def log_sizes(kind, rng, total):
@@ -189,7 +190,127 @@ def case_long(c, rng):
     done["long"] += 1
 
 
-CASES = [case_log, case_batch, case_log, case_blocks, case_log, case_long]
+def around(rng, centre, spread):
+    return max(0, int(centre + rng.integers(-spread, spread + 1)))
+
+
+def case_host(c, rng):
+    """Host-pointer entry points, with sizes drawn around the points where the engine changes route: 64 KiB and
+    1 MiB of input (zero-copy block, in-place reads of pinned memory), 4096 items, 80 KiB spans (long-buffer
+    route), 16 KiB for Extend, 16 MiB (staged upload from pageable memory)."""
+    import ctypes as C
+    L = capi.lib
+    what = int(rng.integers(0, 4))
+    pinned = bool(rng.integers(0, 2))
+    if what == 0:  # Extend over one buffer
+        n = around(rng, int(rng.choice([0, 16, 16 << 10, 64 << 10, 1 << 20, 5 << 20, 16 << 20])), 40)
+        init = int(rng.integers(0, 1 << 32))
+        host = O.splitmix((n + 64) & ~7, int(rng.integers(1, 1000)))
+        lead = int(rng.integers(0, 32))
+        handle = None
+        buf = host
+        if pinned:
+            handle = L.tcrc_host_alloc(eng.ctx, host.size)
+            buf = np.ctypeslib.as_array(C.cast(handle, C.POINTER(C.c_uint8)), shape=(host.size,))
+            buf[:] = host
+        out = C.c_uint32(0)
+        capi.check(L.tcrc_extend(eng.ctx, init, C.c_void_p(buf.ctypes.data + lead), n, C.byref(out)))
+        if handle:
+            L.tcrc_host_free(eng.ctx, C.c_void_p(handle))
+        assert out.value == O.extend(init, host[lead:lead + n], "hw"), ("host extend", c, n, lead, pinned)
+    elif what == 3:  # a log image
+        total = around(rng, int(rng.choice([1000, 32768, 65536, 1 << 20, 16 << 20])), 3000)
+        recycle = bool(rng.integers(0, 2))
+        t = O.OracleLog(recycle=recycle, log_number=9)
+        kind = int(rng.integers(0, 6))
+        for n in log_sizes(kind, rng, min(max(total, 8), (2 << 20) if kind == 0 else (1 << 30))):
+            o = int(rng.integers(0, len(FILL) - n)) if n < len(FILL) else 0
+            t.write(FILL[o:o + n])
+        img = np.frombuffer(t.contents(), dtype=np.uint8).copy()
+        t.close()
+        if img.size == 0:
+            return
+        for pos in rng.integers(0, img.size, int(rng.integers(0, 5))):
+            img[int(pos)] ^= 1 << int(rng.integers(0, 8))
+        nb = (img.size + 32767) // 32768
+        want = np.zeros((nb, 4), dtype=np.uint32)
+        O.lib().oracle_wal_scan_blocks(img.ctypes.data, img.size, 9, want.ctypes.data)
+        got = np.zeros((nb, 4), dtype=np.uint32)
+        counts = np.zeros(3, np.uint64)
+        nrec = C.c_uint64(0)
+        capi.check(L.tcrc_host_wal_verify(eng.ctx, C.c_void_p(img.ctypes.data), img.size, 9, C.c_void_p(got.ctypes.data),
+                                          C.c_void_p(counts.ctypes.data), C.byref(nrec)))
+        assert (got == want).all(), ("host log", c, img.size)
+        assert nrec.value == int(want[:, 0].sum()), ("host log records", c)
+    else:  # descriptor batches, stamped (what == 1) or verified against the values stored behind them (what == 2)
+        shape = int(rng.integers(0, 5))
+        if shape == 0:    # one fetched block
+            n, maxlen = 1, int(rng.choice([4096, 8192, 65536, 81920, 300000]))
+        elif shape == 1:  # a handful of meta blocks, one of them long
+            n, maxlen = int(rng.integers(2, 9)), int(rng.choice([5000, 81919, 81920, 400000]))
+        elif shape == 2:  # around 4096 items
+            n, maxlen = around(rng, 4096, 3), 200
+        elif shape == 3:  # around 1 MiB of input
+            n, maxlen = int(rng.integers(10, 300)), 9000
+        else:             # an extent of blocks above the staging threshold
+            n, maxlen = int(rng.integers(3000, 6000)), 4200
+        lens = rng.integers(maxlen // 2, maxlen + 1, n).astype(np.uint32)
+        gap = 5 + int(rng.integers(0, 3))
+        offs = (np.cumsum(lens.astype(np.uint64) + gap) - lens - gap).astype(np.uint64) + int(rng.integers(0, 16))
+        total = int(offs[-1] + lens[-1] + gap)
+        if shape == 3:
+            total = max(total, around(rng, 1 << 20, 64))
+        if shape == 0 and rng.random() < 0.5:
+            total = max(total, around(rng, 64 << 10, 8))
+        host = O.splitmix((total + 15) & ~7, int(rng.integers(1, 1000)))[:total]
+        inits = np.zeros(n, np.uint32) if what == 2 else rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+        use_suffix = shape != 1 and rng.random() < 0.6
+        sfx = rng.integers(0, 256, n).astype(np.uint8) if use_suffix else None
+        want = O.batch_extend(host, offs, lens, inits, sfx, True)
+        d = (capi.Desc * n)()
+        for i in range(n):
+            d[i].offset, d[i].len, d[i].init = int(offs[i]), int(lens[i]), int(inits[i])
+        handle = None
+        buf = host.copy()
+        if pinned:
+            handle = L.tcrc_host_alloc(eng.ctx, total)
+            buf = np.ctypeslib.as_array(C.cast(handle, C.POINTER(C.c_uint8)), shape=(total,))
+            buf[:] = host
+        sp = None if sfx is None else C.c_void_p(sfx.ctypes.data)
+        if what == 1:
+            out = np.zeros(n, np.uint32)
+            capi.check(L.tcrc_host_batch_stamp(eng.ctx, C.c_void_p(buf.ctypes.data), total, d, n, sp, capi.F_MASK,
+                                               C.c_void_p(out.ctypes.data)))
+            bad = np.nonzero(out != want)[0]
+            assert bad.size == 0, ("host stamp", c, shape, n, total, pinned, bad[:5])
+        else:
+            # stored values behind every span (behind its suffix byte when there is one), a few of them wrong
+            wrong = set(rng.integers(0, n, int(rng.integers(0, 3))).tolist())
+            for i in range(n):
+                at = int(offs[i] + lens[i])
+                if sfx is not None:
+                    buf[at] = sfx[i]
+                    at += 1
+                v = int(want[i]) ^ (0x100 if i in wrong else 0)
+                buf[at:at + 4] = np.frombuffer(np.uint32(v).tobytes(), np.uint8)
+            ok = np.full(n, 7, np.uint8)
+            got = np.zeros(n, np.uint32)
+            counts = np.zeros(3, np.uint64)
+            capi.check(L.tcrc_host_batch_verify(eng.ctx, C.c_void_p(buf.ctypes.data), total, d, n, sp, capi.F_EXPECT_AFTER,
+                                                None, C.c_void_p(got.ctypes.data), C.c_void_p(ok.ctypes.data),
+                                                C.c_void_p(counts.ctypes.data)))
+            assert (got == want).all(), ("host verify values", c, shape, n, total, pinned)
+            verdict = np.array([0 if i in wrong else 1 for i in range(n)], np.uint8)
+            assert (ok == verdict).all(), ("host verify verdicts", c, shape, n, total, pinned)
+            assert int(counts[0]) == len(wrong) and int(counts[2]) == n, ("host verify counts", c, counts)
+            if wrong:
+                assert int(counts[1]) == min(wrong), ("host verify first bad", c)
+        if handle:
+            L.tcrc_host_free(eng.ctx, C.c_void_p(handle))
+    done["host"] += 1
+
+
+CASES = [case_log, case_batch, case_host, case_blocks, case_log, case_long, case_host]
 t_end = time.perf_counter() + budget
 t_print = time.perf_counter() + 5
 while time.perf_counter() < t_end:
