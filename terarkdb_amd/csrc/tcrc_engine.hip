@@ -1305,16 +1305,22 @@ int run_wal_scan(tcrc_ctx* ctx, WalScanParams p, void* stream) {
   const int gi = geo_index(8);
   p.tab_main = ctx->d_tab_main[gi];
   p.tab_aux = ctx->d_tab_aux[gi];
-  for (uint32_t q = 0; q < 16; ++q)
-    for (uint32_t l = 0; l < 4; ++l) p.pow_piece[q * 4 + l] = tcrc::gf2_xpow(8ull * kWalPiece * q + 8ull * l);
+  // the multipliers of the pieces: worked out once per process (64 modular powers take tens of microseconds on
+  // the host, as long as the scan of a small log takes on the device)
+  struct PiecePowers {
+    uint32_t v[64];
+    PiecePowers() {
+      for (uint32_t q = 0; q < 16; ++q)
+        for (uint32_t l = 0; l < 4; ++l) v[q * 4 + l] = tcrc::gf2_xpow(8ull * kWalPiece * q + 8ull * l);
+    }
+  };
+  static const PiecePowers piece_powers;
+  memcpy(p.pow_piece, piece_powers.v, sizeof(p.pow_piece));
   p.trace = (unsigned long long*)ctx->wal_trace;
   // chunks of up to 64 blocks (one per walker lane), at least two chunks per workgroup
   p.chunk_shift = 6;
   while (p.chunk_shift > 0 && (p.nblocks >> p.chunk_shift) < 2u * (uint32_t)ctx->cus) --p.chunk_shift;
-  if (const char* e = getenv("TCRC_WAL_CHUNK_SHIFT")) {  // experiments only
-    const int v = atoi(e);
-    if (v >= 0 && v <= 20) p.chunk_shift = (uint32_t)v;
-  }
+  if (ctx->forced_wal_chunk_shift >= 0) p.chunk_shift = (uint32_t)ctx->forced_wal_chunk_shift;
   const unsigned wgs = p.nblocks < (uint32_t)ctx->cus ? p.nblocks : (unsigned)ctx->cus;
   hipStream_t s = (hipStream_t)stream;
   if (ctx->nontemporal)
@@ -1389,6 +1395,10 @@ int tcrc_init(int device, tcrc_ctx** out) {
   ctx->device = device;
   ctx->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (const char* e = getenv("TCRC_LANES_PER_BUFFER")) ctx->forced_g = atoi(e);
+  if (const char* e = getenv("TCRC_WAL_CHUNK_SHIFT")) {
+    const int v = atoi(e);
+    if (v >= 0 && v <= 20) ctx->forced_wal_chunk_shift = v;
+  }
   if (const char* e = getenv("TCRC_NONTEMPORAL")) ctx->nontemporal = atoi(e) != 0;
   if (const char* e = getenv("TCRC_NO_POLL")) ctx->poll_completion = atoi(e) == 0;
   for (int gi = 0; gi < kGeoCount; ++gi) {

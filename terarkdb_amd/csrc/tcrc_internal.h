@@ -286,6 +286,7 @@ struct tcrc_ctx {
   int device = -1;
   int cus = 0;
   int forced_g = 0;
+  int forced_wal_chunk_shift = -1;  // >= 0: set for experiments only (TCRC_WAL_CHUNK_SHIFT)
   bool nontemporal = true;  // batch data is read once: keep it from displacing other lines in L2/MALL
   uint32_t* d_tab_main[tcrc_internal::kGeoCount] = {};
   uint32_t* d_tab_aux[tcrc_internal::kGeoCount] = {};
