@@ -147,8 +147,8 @@ int tcrc_dev_extend_long(tcrc_ctx* ctx, const void* d_base, const tcrc_desc* h_d
 /* tcrc_dev_extend_long for callers that cannot allocate (code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments and results,
  * with these limits: at most 64 buffers per call (TCRC_ERR_TOO_LARGE beyond), each up to 1 GiB.  The
- * call only enqueues one memset and one kernel on `stream`: it allocates nothing, issues no copy command
- * and does not synchronise, so d_out is complete once the stream has run (the caller synchronises).
+ * call only enqueues two kernels (one clears the lines) on `stream`: it allocates nothing, issues no copy
+ * command and does not synchronise, so d_out is complete once the stream has run (the caller synchronises).
  * The partial results live in 8 KiB of the library's static device memory (each GPU holds its own copy
  * for the life of the process; the same array holds the 272 KiB of power tables built at tcrc_init).
  * Every call on a GPU shares those 8 KiB: calls that overlap on one GPU - different streams without an

@@ -58,6 +58,15 @@ __global__ __launch_bounds__(1024) void k_pow_tables(uint32_t* tables) {
   }
 }
 
+// Zeroes `words` dwords.  The entry point that allocates nothing clears its accumulator lines with this kernel
+// and not with hipMemsetAsync: with the memset recorded into a HIP graph in front of the kernel, only the first
+// launch of the graph wrote its results (ROCm 7.2; from the second launch on d_out was left as it was, which
+// is what lines cleared under the kernel's arrivals look like).  With a kernel doing the clearing every launch
+// of the graph writes them.
+__global__ __launch_bounds__(256) void k_zero_words(uint32_t* p, uint32_t words) {
+  for (uint32_t i = threadIdx.x; i < words; i += 256u) p[i] = 0u;
+}
+
 // Segment length for a call.  512 bytes up to 2 MiB in all: short segments spread a small call over many waves
 // (what the waves of a workgroup deliver to a buffer is folded in LDS before it reaches the buffer's accumulator
 // line, so the arrivals that queue there number one per workgroup).  Then 1 KiB and 2 KiB, which keep a call of
@@ -260,8 +269,8 @@ extern "C" int tcrc_dev_extend_long(tcrc_ctx* ctx, const void* d_base, const tcr
 
 // The same for callers that must not allocate (a HIP graph being captured, a serving loop, a harness that
 // forbids it): at most kLongInline buffers, accumulator lines in the library's static device memory, one
-// memset and one kernel enqueued on `stream`, nothing else - no allocation, no copy command, no
-// synchronisation.  Results are in d_out once the stream has run.  Calls that overlap on one GPU share the
+// small kernel that clears the lines and the checksum kernel enqueued on `stream`, nothing else - no allocation,
+// no copy command, no synchronisation.  Results are in d_out once the stream has run.  Calls that overlap on one GPU share the
 // static lines and race: keep them on one stream, or order them with events.
 extern "C" int tcrc_dev_extend_long_noalloc(tcrc_ctx* ctx, const void* d_base, const tcrc_desc* h_desc, uint64_t n,
                                             uint32_t segment_len, uint32_t* d_out, void* stream) {
@@ -279,7 +288,8 @@ extern "C" int tcrc_dev_extend_long_noalloc(tcrc_ctx* ctx, const void* d_base, c
   ctx->st_long_bytes.fetch_add(total, std::memory_order_relaxed);
   hipStream_t s = (hipStream_t)stream;
   // the lines keep whatever an earlier call (or one that was cut short) left in them
-  HIP_TRY(hipMemsetAsync(ctx->d_static, 0, (size_t)kStaticAccWords * 4, s));
+  hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(256), 0, s, ctx->d_static, kStaticAccWords);
+  HIP_TRY(hipGetLastError());
   la.acc = ctx->d_static;
   BatchParams p{};
   p.base = (const uint8_t*)d_base;

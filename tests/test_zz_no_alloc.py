@@ -69,3 +69,37 @@ def test_limits_and_no_allocation_side_effects(eng):
     assert free0 == free1
     want = O.batch_extend(host, np.array([3, 9], np.uint64), np.array([1 << 19, 77777], np.uint32), np.array([0, 1], np.uint32))
     assert (out[:2].cpu().numpy().view(np.uint32) == want).all()
+
+
+def test_entry_point_is_captured_into_a_graph_and_replayed():
+    """The callers the entry point is for include a HIP graph under capture: the call's memset and kernel are
+    recorded into the graph (nothing is allocated, copied or synchronised), and every replay leaves the
+    checksums of whatever the buffers hold at that time."""
+    import gpu_util as G
+    eng = G.engine()  # a context of its own: closed at the end
+    host = O.splitmix(4 << 20, 77)
+    dev = G.to_dev(host)
+    offs, lens, inits = [5, 1 << 20, 3 << 20], [(1 << 20) - 9, 2 << 20, 70001], [0, 0xdeadbeef, 7]
+    out = torch.zeros(3, dtype=torch.int32, device="cuda")
+    # one ordinary call first, so that nothing is set up for the first time inside the capture
+    eng.extend_long(dev, offs, lens, inits, out, noalloc=True)
+    torch.cuda.synchronize()
+    out.zero_()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        eng.extend_long(dev, offs, lens, inits, out, noalloc=True, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    want = O.batch_extend(host, np.array(offs, np.uint64), np.array(lens, np.uint32), np.array(inits, np.uint32))
+    for rep in range(3):
+        out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert (out.cpu().numpy().view(np.uint32) == want).all(), rep
+    # the graph reads the buffers where they lie: other bytes, other checksums
+    host2 = O.splitmix(4 << 20, 78)
+    dev.copy_(torch.from_numpy(host2))
+    g.replay()
+    torch.cuda.synchronize()
+    want2 = O.batch_extend(host2, np.array(offs, np.uint64), np.array(lens, np.uint32), np.array(inits, np.uint32))
+    assert (out.cpu().numpy().view(np.uint32) == want2).all()
+    eng.close()
