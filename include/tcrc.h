@@ -222,7 +222,8 @@ int tcrc_dev_wal_list(tcrc_ctx* ctx, const void* d_img, uint64_t size, uint64_t 
  * tails shorter than a header, and Mask(crc32c(type | [log number] | payload)) in every header.
  * Record i is the h_recs[i].len bytes at d_src + h_recs[i].offset (h_recs[i].init is ignored).
  * block_offset is the position inside the current 32 KiB block at which the image continues an
- * existing log (0 for a new file); *block_offset_out (may be NULL) is that position after the call.
+ * existing log (0 for a new file); *block_offset_out (may be NULL) is that position after the call
+ * (always below 32768: 0 when the image ends exactly at a block boundary), ready to be passed to the next call.
  * *h_written receives the image size; tcrc_wal_framed_size gives it beforehand.  d_dst must not
  * overlap d_src.  Returns with the image complete. */
 int tcrc_dev_wal_frame(tcrc_ctx* ctx, const void* d_src, const tcrc_desc* h_recs, uint64_t n, uint64_t log_number,

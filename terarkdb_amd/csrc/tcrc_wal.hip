@@ -161,7 +161,9 @@ uint64_t plan_frames(const tcrc_desc* recs, uint64_t n, bool recycle, uint32_t b
       if (left == 0) break;
     }
   }
-  if (block_offset_out) *block_offset_out = bo;
+  // an image that ends exactly at a block boundary continues at offset 0 of the next block (the writer's own
+  // counter stands at 32768 then, db/log_writer.cc:58-80 turns it into 0 at the next record)
+  if (block_offset_out) *block_offset_out = bo == kLogBlock ? 0u : bo;
   if (physical) *physical = phys;
   return pos;
 }

@@ -173,6 +173,31 @@ def _oracle_image(records, recycle, log_number, prefix=b""):
 
 
 @pytest.mark.parametrize("recycle", [False, True])
+def test_device_framing_continues_after_an_image_that_ends_at_a_block_boundary(recycle):
+    """A call whose image fills its last block to the byte hands back block offset 0 (the reference's writer
+    starts the next block at its next record, db/log_writer.cc:58-80), and the next call takes that offset."""
+    import gpu_util as G
+    eng = G.engine()
+    hs = 11 if recycle else 7
+    src = O.splitmix(1 << 17, 5)
+    first = [src[:32768 - hs].tobytes()]             # one FULL record, exactly one block
+    rest = [src[100:100 + 70000].tobytes(), b"", src[7:9].tobytes()]
+    dsrc = G.to_dev(src)
+    want1, _ = _oracle_image(first, recycle, 9)
+    want2, start = _oracle_image(rest, recycle, 9, prefix=first)
+    assert len(want1) == 32768 and start == 0
+    dst = torch.zeros(len(want1) + len(want2) + 8, dtype=torch.uint8, device="cuda")
+    w1, bo1, p1 = eng.wal_frame(dsrc, [0], [32768 - hs], 9, recycle, dst)
+    assert (w1, bo1, p1) == (32768, 0, 1)
+    w2, bo2, _ = eng.wal_frame(dsrc, [100, 0, 7], [70000, 0, 2], 9, recycle, dst[w1:], block_offset=bo1)
+    torch.cuda.synchronize()
+    got = dst.cpu().numpy()
+    assert got[:w1].tobytes() == want1 and got[w1:w1 + w2].tobytes() == want2
+    assert bo2 == (w1 + w2) % 32768
+    eng.close()
+
+
+@pytest.mark.parametrize("recycle", [False, True])
 def test_device_framing_is_byte_identical_to_the_cpu_writer(recycle):
     import ctypes as C
     import gpu_util as G

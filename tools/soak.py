@@ -6,8 +6,8 @@ budget.  Every case draws its own shape from the case number, so a failure names
 Cases rotate over: log scans (size distributions from tiny records to whole-block fragments and the skewed
 mix, both header kinds, clean and damaged, whole and truncated images), descriptor batches (any offset, any
 length, initial values, suffix bytes, masked or not, in-image expectations), uniform blocks, and long buffers
-(both entry points, random segment lengths), and the host-pointer entry points with sizes around the points
-where the engine changes route.  Prints a progress line every few seconds; exits non-zero at the
+(both entry points, random segment lengths), the host-pointer entry points with sizes around the points
+where the engine changes route, and device-side framing followed by a scan and a record list.  Prints a progress line every few seconds; exits non-zero at the
 first difference."""
 import os, sys, time
 import numpy as np, torch
@@ -20,7 +20,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 case = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 eng = capi.Engine(0)
 FILL = O.splitmix(1 << 20, 11).tobytes()
-done = {"log": 0, "batch": 0, "blocks": 0, "long": 0, "host": 0}
+done = {"log": 0, "batch": 0, "blocks": 0, "long": 0, "host": 0, "frame": 0}
 
 
 def log_sizes(kind, rng, total):
@@ -310,7 +310,71 @@ def case_host(c, rng):
     done["host"] += 1
 
 
-CASES = [case_log, case_batch, case_host, case_blocks, case_log, case_long, case_host]
+REC = np.dtype([("offset", "<u8"), ("length", "<u4"), ("type", "u1"), ("status", "u1"), ("header_size", "<u2")])
+
+
+def case_frame(c, rng):
+    """Records framed on the device, in two calls (the second continues at the block offset the first left),
+    against the bytes of the CPU writer; then damaged, scanned and listed record by record."""
+    recycle = bool(rng.integers(0, 2))
+    lognum = int(rng.integers(1, 1 << 31))
+    kind = int(rng.integers(0, 6))
+    total = int(rng.integers(1, 1 << int(rng.integers(10, 23))))
+    lens = log_sizes(kind, rng, min(total, (1 << 20) if kind == 0 else (1 << 30)))
+    src = O.splitmix((sum(lens) + 64 + 7) & ~7, int(rng.integers(1, 1000)))
+    offs, pos = [], int(rng.integers(0, 8))
+    for ln in lens:
+        offs.append(pos)
+        pos += ln
+    t = O.OracleLog(recycle=recycle, log_number=lognum)
+    half = int(rng.integers(0, len(lens) + 1))
+    for i in range(half):
+        t.write(src[offs[i]:offs[i] + lens[i]].tobytes())
+    first = t.written_bytes()
+    for i in range(half, len(lens)):
+        t.write(src[offs[i]:offs[i] + lens[i]].tobytes())
+    want = np.frombuffer(t.contents(), dtype=np.uint8).copy()
+    t.close()
+    dsrc = torch.from_numpy(src).cuda()
+    dst = torch.full((want.size + 64,), 0xAB, dtype=torch.uint8, device="cuda")
+    w1, bo1, p1 = eng.wal_frame(dsrc, offs[:half], lens[:half], lognum, recycle, dst)
+    assert (w1, bo1) == (first, first % 32768), ("frame first part", c, w1, bo1, first)
+    w2, bo2, p2 = eng.wal_frame(dsrc, offs[half:], lens[half:], lognum, recycle, dst[first:], block_offset=bo1)
+    torch.cuda.synchronize()
+    got = dst.cpu().numpy()
+    assert w1 + w2 == want.size and bo2 == want.size % 32768, ("frame sizes", c, w1, w2, want.size)
+    assert (got[:want.size] == want).all(), ("frame bytes", c, kind, recycle, half, int(np.nonzero(got[:want.size] != want)[0][0]))
+    assert (got[want.size:] == 0xAB).all(), ("frame wrote past its image", c)
+    if want.size == 0:
+        done["frame"] += 1
+        return
+    # damage, scan, list
+    img = want.copy()
+    for at in rng.integers(0, img.size, int(rng.integers(0, 20))):
+        img[int(at)] ^= 1 << int(rng.integers(0, 8))
+    dev = torch.from_numpy(img).cuda()
+    nb = (img.size + 32767) // 32768
+    want_blocks = O.wal_scan_blocks(img, lognum)
+    accepted, n_acc = O.list_physical(img.tobytes(), lognum)
+    blocks = torch.zeros((nb, 4), dtype=torch.int32, device="cuda")
+    counts = torch.zeros(capi.CNT_WORDS, dtype=torch.int64, device="cuda")
+    eng.counts_reset(counts)
+    n = eng.wal_verify(dev, img.size, lognum, blocks, counts)
+    assert n == int(want_blocks[:, 0].sum()), ("frame scan records", c)
+    recs = torch.zeros(max(n, 1) * 16, dtype=torch.uint8, device="cuda")
+    assert eng.wal_list(dev, img.size, lognum, blocks, recs, n) == n, ("list count", c)
+    torch.cuda.synchronize()
+    r = recs.cpu().numpy().view(REC)[:n]
+    ok = r[r["status"] == 1]
+    assert len(ok) == n_acc, ("list accepted", c, len(ok), n_acc)
+    assert (ok["offset"] == accepted[:, 0]).all() and (ok["type"] == accepted[:, 1]).all() and \
+        (ok["length"] == accepted[:, 2]).all(), ("list records", c)
+    if img.size == want.size and (img == want).all():
+        assert n == p1 + p2 and n_acc == n, ("clean image", c, n, p1, p2)
+    done["frame"] += 1
+
+
+CASES = [case_log, case_batch, case_host, case_blocks, case_log, case_long, case_host, case_frame]
 t_end = time.perf_counter() + budget
 t_print = time.perf_counter() + 5
 while time.perf_counter() < t_end:
