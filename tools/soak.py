@@ -7,7 +7,8 @@ Cases rotate over: log scans (size distributions from tiny records to whole-bloc
 mix, both header kinds, clean and damaged, whole and truncated images), descriptor batches (any offset, any
 length, initial values, suffix bytes, masked or not, in-image expectations), uniform blocks, and long buffers
 (both entry points, random segment lengths), the host-pointer entry points with sizes around the points
-where the engine changes route, and device-side framing followed by a scan and a record list.  Prints a progress line every few seconds; exits non-zero at the
+where the engine changes route, device-side framing followed by a scan and a record list, and the
+log::Writer / log::Reader classes beside the CPU writer and reader.  Prints a progress line every few seconds; exits non-zero at the
 first difference."""
 import os, sys, time
 import numpy as np, torch
@@ -20,7 +21,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 case = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 eng = capi.Engine(0)
 FILL = O.splitmix(1 << 20, 11).tobytes()
-done = {"log": 0, "batch": 0, "blocks": 0, "long": 0, "host": 0, "frame": 0}
+done = {"log": 0, "batch": 0, "blocks": 0, "long": 0, "host": 0, "frame": 0, "classes": 0}
 
 
 def log_sizes(kind, rng, total):
@@ -374,7 +375,56 @@ def case_frame(c, rng):
     done["frame"] += 1
 
 
-CASES = [case_log, case_batch, case_host, case_blocks, case_log, case_long, case_host, case_frame]
+def case_classes(c, rng):
+    """The engine's log::Writer and log::Reader (through the C wrappers) beside the CPU writer and reader: the
+    same records, the same file bytes; then the same damage to both files and the same records, dropped bytes
+    and reports out of both readers, under every recovery mode."""
+    import engine_log
+    recycle = bool(rng.integers(0, 2))
+    lognum = int(rng.integers(1, 1 << 20))
+    manual = bool(rng.integers(0, 2))
+    bulk = bool(rng.integers(0, 2))
+    kind = int(rng.integers(0, 6))
+    total = int(rng.integers(1, 1 << int(rng.integers(8, 21))))
+    lens = log_sizes(kind, rng, min(total, (1 << 17) if kind == 0 else (1 << 30)))
+    e = engine_log.EngineLog(recycle=recycle, log_number=lognum, ctx=eng.ctx, manual_flush=manual, bulk_image=bulk)
+    o = O.OracleLog(recycle=recycle, log_number=lognum)
+    for n in lens:
+        at = int(rng.integers(0, len(FILL) - n)) if n < len(FILL) else 0
+        e.write(FILL[at:at + n])
+        o.write(FILL[at:at + n])
+    if manual:
+        e.flush()
+    a, b = e.contents(), o.contents()
+    assert a == b, ("writer bytes", c, kind, recycle, manual, len(a), len(b))
+    size = len(a)
+    what = int(rng.integers(0, 3))
+    if what == 1 and size:
+        for at in rng.integers(0, size, int(rng.integers(1, 6))):
+            d = int(rng.integers(1, 256))
+            e.increment_byte(int(at), d)
+            o.increment_byte(int(at), d)
+    elif what == 2 and size > 1:
+        cut = int(rng.integers(1, min(size, 70000)))
+        e.shrink_size(cut)
+        o.shrink_size(cut)
+    # (the reference's reader never gets past an old record when it skips every corrupted one, and a damaged
+    # type byte can make any record an old one: that mode only where no byte was changed)
+    mode = int(rng.integers(0, 3 if what == 1 else 4))
+    for k in range(len(lens) + 3):
+        ra, rb = e.read(mode), o.read(mode)
+        assert ra == rb, ("reader record", c, k, kind, recycle, what, mode, bulk,
+                          ra if ra == "EOF" else len(ra), rb if rb == "EOF" else len(rb))
+        if ra == "EOF":
+            break
+    assert e.dropped_bytes() == o.dropped_bytes(), ("dropped bytes", c, e.dropped_bytes(), o.dropped_bytes())
+    assert e.report_message() == o.report_message(), ("report", c, e.report_message(), o.report_message())
+    e.close()
+    o.close()
+    done["classes"] += 1
+
+
+CASES = [case_log, case_batch, case_host, case_blocks, case_log, case_long, case_host, case_frame, case_classes]
 t_end = time.perf_counter() + budget
 t_print = time.perf_counter() + 5
 while time.perf_counter() < t_end:
