@@ -7,8 +7,8 @@ Cases rotate over: log scans (size distributions from tiny records to whole-bloc
 mix, both header kinds, clean and damaged, whole and truncated images), descriptor batches (any offset, any
 length, initial values, suffix bytes, masked or not, in-image expectations), uniform blocks, and long buffers
 (both entry points, random segment lengths), the host-pointer entry points with sizes around the points
-where the engine changes route, device-side framing followed by a scan and a record list, and the
-log::Writer / log::Reader classes beside the CPU writer and reader.  Prints a progress line every few seconds; exits non-zero at the
+where the engine changes route, device-side framing followed by a scan and a record list, the
+log::Writer / log::Reader classes beside the CPU writer and reader, and whole-file table verification.  Prints a progress line every few seconds; exits non-zero at the
 first difference."""
 import os, sys, time
 import numpy as np, torch
@@ -21,7 +21,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 case = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 eng = capi.Engine(0)
 FILL = O.splitmix(1 << 20, 11).tobytes()
-done = {"log": 0, "batch": 0, "blocks": 0, "long": 0, "host": 0, "frame": 0, "classes": 0}
+done = {"log": 0, "batch": 0, "blocks": 0, "long": 0, "host": 0, "frame": 0, "classes": 0, "table": 0}
 
 
 def log_sizes(kind, rng, total):
@@ -424,7 +424,35 @@ def case_classes(c, rng):
     done["classes"] += 1
 
 
-CASES = [case_log, case_batch, case_host, case_blocks, case_log, case_long, case_host, case_frame, case_classes]
+def case_table(c, rng):
+    """Whole-file verification of a block-based table written by the test-file writer (every index and footer
+    variant), clean or with a few flipped bits anywhere in front of the footer: the status text must be the one
+    the reference's visiting order gives (first failing block), worked out on the CPU."""
+    import tempfile
+    import sst_cases, sst_files as S, sst_verify_util as U
+    kw = dict(sst_cases.VARIANTS[int(rng.integers(0, len(sst_cases.VARIANTS)))])
+    if kw.get("n_data", 40) > 1:
+        kw["n_data"] = int(rng.integers(2, 120))
+    kw["seed"] = int(rng.integers(1, 1 << 30))
+    kw["block_bytes"] = int(rng.choice([300, 1000, 4096, 16384]))
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "%06d.sst" % (c % 1000000))
+        lay = S.build_table(path, **kw)
+        size = os.path.getsize(path)
+        footer = 48 if kw.get("legacy_footer") else 53
+        if size > footer:
+            for _ in range(int(rng.integers(0, 4))):
+                S.flip(path, int(rng.integers(0, size - footer)), int(rng.integers(0, 8)))
+        want = S.expected_status(lay)
+        rc, msg, st = U.verify_with_engine(eng)(path, extent_bytes=int(rng.choice([0, 1 << 16, 1 << 20])),
+                                                read_threads=int(rng.choice([0, 1, 4])))
+        assert msg == want, ("table status", c, kw, msg, want)
+        assert rc == (0 if want == "OK" else 1), ("table rc", c, rc)
+    done["table"] += 1
+
+
+CASES = [case_log, case_batch, case_host, case_blocks, case_log, case_long, case_host, case_frame, case_classes,
+         case_table]
 t_end = time.perf_counter() + budget
 t_print = time.perf_counter() + 5
 while time.perf_counter() < t_end:
