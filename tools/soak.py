@@ -8,7 +8,8 @@ mix, both header kinds, clean and damaged, whole and truncated images), descript
 length, initial values, suffix bytes, masked or not, in-image expectations), uniform blocks, and long buffers
 (both entry points, random segment lengths), the host-pointer entry points with sizes around the points
 where the engine changes route, device-side framing followed by a scan and a record list, the
-log::Writer / log::Reader classes beside the CPU writer and reader, and whole-file table verification.  Prints a progress line every few seconds; exits non-zero at the
+log::Writer / log::Reader classes beside the CPU writer and reader, whole-file table verification, and
+whole-file checksums through buffers of several sizes.  Prints a progress line every few seconds; exits non-zero at the
 first difference."""
 import os, sys, time
 import numpy as np, torch
@@ -21,7 +22,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 case = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 eng = capi.Engine(0)
 FILL = O.splitmix(1 << 20, 11).tobytes()
-done = {"log": 0, "batch": 0, "blocks": 0, "long": 0, "host": 0, "frame": 0, "classes": 0, "table": 0}
+done = {"log": 0, "batch": 0, "blocks": 0, "long": 0, "host": 0, "frame": 0, "classes": 0, "table": 0, "file": 0}
 
 
 def log_sizes(kind, rng, total):
@@ -451,8 +452,31 @@ def case_table(c, rng):
     done["table"] += 1
 
 
+def case_file(c, rng):
+    """Whole-file crc32c the way the backup engine computes it: a file of a random size read through buffers of a
+    random size (sizes around the buffer size and its multiples), with and without a size limit."""
+    import ctypes as C
+    import tempfile
+    L = capi.lib
+    buf = int(rng.choice([4096, 65536, 1 << 20, 5 << 20]))
+    size = max(0, int(rng.choice([0, 1, buf - 1, buf, buf + 1, 2 * buf, 3 * buf + 17, int(rng.integers(0, 4 * buf))])))
+    data = O.splitmix((size + 8) & ~7, int(rng.integers(1, 1000)))[:size]
+    limit = 0 if rng.random() < 0.5 else int(rng.integers(1, size + 10))
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "f.bin")
+        data.tofile(path)
+        crc, got_size = C.c_uint32(0), C.c_uint64(0)
+        msg = C.create_string_buffer(512)
+        rc = L.tcrc_shim_file_checksum(eng.ctx, path.encode(), limit, buf, C.byref(crc), C.byref(got_size), msg, 512)
+        assert rc == 0, ("file checksum", c, msg.value)
+        n = size if limit == 0 else min(size, limit)
+        assert got_size.value == n, ("file size", c, got_size.value, n)
+        assert crc.value == O.value(data[:n], "hw"), ("file crc", c, size, buf, limit)
+    done["file"] += 1
+
+
 CASES = [case_log, case_batch, case_host, case_blocks, case_log, case_long, case_host, case_frame, case_classes,
-         case_table]
+         case_table, case_file]
 t_end = time.perf_counter() + budget
 t_print = time.perf_counter() + 5
 while time.perf_counter() < t_end:
