@@ -8,8 +8,9 @@ mix, both header kinds, clean and damaged, whole and truncated images), descript
 length, initial values, suffix bytes, masked or not, in-image expectations), uniform blocks, and long buffers
 (both entry points, random segment lengths), the host-pointer entry points with sizes around the points
 where the engine changes route, device-side framing followed by a scan and a record list, the
-log::Writer / log::Reader classes beside the CPU writer and reader, whole-file table verification, and
-whole-file checksums through buffers of several sizes.  Prints a progress line every few seconds; exits non-zero at the
+log::Writer / log::Reader classes beside the CPU writer and reader, whole-file table verification,
+whole-file checksums through buffers of several sizes, and block trailers in the shape a table builder hands
+them over.  Prints a progress line every few seconds; exits non-zero at the
 first difference."""
 import os, sys, time
 import numpy as np, torch
@@ -22,7 +23,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 case = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 eng = capi.Engine(0)
 FILL = O.splitmix(1 << 20, 11).tobytes()
-done = {"log": 0, "batch": 0, "blocks": 0, "long": 0, "host": 0, "frame": 0, "classes": 0, "table": 0, "file": 0}
+done = {"log": 0, "batch": 0, "blocks": 0, "long": 0, "host": 0, "frame": 0, "classes": 0, "table": 0, "file": 0, "trailers": 0}
 
 
 def log_sizes(kind, rng, total):
@@ -475,8 +476,35 @@ def case_file(c, rng):
     done["file"] += 1
 
 
+def case_trailers(c, rng):
+    """Block trailers as WriteRawBlock forms them, for the blocks a table builder hands over in one go: sizes from
+    empty to hundreds of KiB (a filter or index block among data blocks), any type byte."""
+    L = capi.lib
+    n = int(rng.integers(1, 1 << int(rng.integers(1, 13))))
+    big = int(rng.choice([200, 9000, 9000, 120000, 600000]))
+    sizes = rng.integers(0, big, size=n).astype(np.uint64)
+    if big > 9000:
+        sizes[rng.integers(0, n, max(1, n // 50))] = int(rng.integers(80000, big))
+        sizes[sizes > 9000] *= (rng.random(int((sizes > 9000).sum())) < 0.05) | (np.arange(int((sizes > 9000).sum())) < 3)
+    types = rng.integers(0, 256, size=n).astype(np.uint8)
+    offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.uint64)
+    base = O.splitmix((int(sizes.sum()) + 16) & ~7, int(rng.integers(1, 1000)))
+    out = np.zeros(5 * n, dtype=np.uint8)
+    rc = L.tcrc_shim_block_trailers(eng.ctx, base.ctypes.data, offs.ctypes.data, sizes.ctypes.data, types.ctypes.data, n, 1,
+                                    out.ctypes.data)
+    assert rc == 0, ("trailers rc", c, rc)
+    want = O.batch_extend(base, offs, sizes.astype(np.uint32), None, types, True)
+    tr = out.reshape(n, 5)
+    got = tr[:, 1].astype(np.uint32) | (tr[:, 2].astype(np.uint32) << 8) | (tr[:, 3].astype(np.uint32) << 16) | \
+        (tr[:, 4].astype(np.uint32) << 24)
+    assert (tr[:, 0] == types).all(), ("trailer type bytes", c)
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, ("trailer values", c, n, bad[:5], sizes[bad[:5]])
+    done["trailers"] += 1
+
+
 CASES = [case_log, case_batch, case_host, case_blocks, case_log, case_long, case_host, case_frame, case_classes,
-         case_table, case_file]
+         case_table, case_file, case_trailers]
 t_end = time.perf_counter() + budget
 t_print = time.perf_counter() + 5
 while time.perf_counter() < t_end:
