@@ -42,12 +42,41 @@ CORRUPT_PER_GIB = 5          # seeded single-bit corruptions per GiB of corpus (
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E peak
 
 
+def host_cpu_facts():
+    """What the CPU baseline ran on: logical CPUs of the machine, CPUs this process may use, the share the
+    box's environment states for worker pools, and the model name."""
+    model = "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    affinity = len(os.sched_getaffinity(0))
+    share = 0
+    for var in ("OMP_NUM_THREADS", "MAX_JOBS"):
+        try:
+            share = int(os.environ.get(var, "0"))
+        except ValueError:
+            share = 0
+        if share > 0:
+            break
+    return {"nproc": os.cpu_count(), "affinity": affinity, "stated_share": share or None, "model": model}
+
+
 def cpu_baseline(seconds_budget=12.0):
     """The CPU oracle's SSE4.2+PCLMUL path on the same workload, timed on this host.
-    Checker code (oracle/) is used here only as the thing a GPU number is shown beside."""
+    Checker code (oracle/) is used here only as the thing a GPU number is shown beside.
+    Threads: every CPU of the affinity mask, or the CPU share the box's environment states for a one-GPU job
+    when that is smaller (the mask shows the whole machine there).  The rate is the best of three timed passes."""
     import oracle_lib as O
     L = O.lib()
-    cores = max(1, min(16, len(os.sched_getaffinity(0))))
+    facts = host_cpu_facts()
+    cores = facts["affinity"]
+    if facts["stated_share"]:
+        cores = min(cores, facts["stated_share"])
+    cores = max(1, cores)
     sample_blocks = 32768  # 256 MiB of the same stream
     buf = O.splitmix(sample_blocks * BLOCK_LEN, SPLITMIX_STATE)
     out = np.empty(sample_blocks, dtype=np.uint32)
@@ -71,17 +100,22 @@ def cpu_baseline(seconds_budget=12.0):
         return time.perf_counter() - t0
 
     run(1, 1)  # warm
-    t1 = run(1, 2)
+    t1 = min(run(1, 2) for _ in range(3))
     single = 2 * sample_blocks * (BLOCK_LEN + 1) / t1 / 1e9
-    passes = max(2, int(seconds_budget * 0.6 / max(t1 / 2 / cores, 1e-3) / 1.0))
-    passes = min(passes, 600)
-    tn = run(cores, passes)
-    multi = passes * (sample_blocks // cores) * cores * (BLOCK_LEN + 1) / tn / 1e9
+    # three timed passes of about a fifth of the budget each
+    passes = max(2, int(seconds_budget * 0.2 / max(t1 / 2 / cores, 1e-3)))
+    passes = min(passes, 200)
+    run(cores, 2)  # warm all threads
+    times = [run(cores, passes) for _ in range(3)]
+    rates = [passes * (sample_blocks // cores) * cores * (BLOCK_LEN + 1) / t / 1e9 for t in times]
     return {
-        "value": round(multi, 2), "unit": "GB/s", "cores": cores, "kind": "port",
+        "value": round(max(rates), 2), "unit": "GB/s", "cores": cores, "kind": "port",
         "single_core_value": round(single, 2),
-        "sample": f"{sample_blocks} x {BLOCK_LEN} B blocks (256 MiB of the same splitmix stream), "
-                  f"{passes} passes on {cores} threads, static block-range split; "
+        "passes_gbs": [round(r, 1) for r in rates],
+        "nproc": facts["nproc"], "affinity_cpus": facts["affinity"], "stated_cpu_share": facts["stated_share"],
+        "cpu_model": facts["model"],
+        "sample": f"{sample_blocks} x {BLOCK_LEN} B blocks (256 MiB of the same splitmix stream), best of 3 timed "
+                  f"runs of {passes} passes on {cores} threads, static block-range split; "
                   f"oracle SSE4.2 crc32 + PCLMUL 3-way path (hw={hw})",
     }
 
@@ -262,12 +296,28 @@ def main():
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
     value = args.steps * TOTAL_BLOCKS * (BLOCK_LEN + 1) / elapsed / 1e9  # all ranks' units / slowest rank's time
 
+    # Median launch duration, measured AFTER the timed region (an event pair around every launch would sit
+    # between the launches of the timed steps): the same launch, each one bracketed by its own events while the
+    # stream stays busy.
+    n_med = max(args.steps, 20)
+    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_med)]
+    for a, b in pairs:
+        a.record()
+        step()
+        b.record()
+    torch.cuda.synchronize()
+    median_ms = float(np.median([a.elapsed_time(b) for a, b in pairs]))
+
     if rank == 0:
         traffic = None
+        traffic_source = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath) and N_BLOCKS == PER_GIB:  # the counters were collected on the 1 GiB launch
             try:
-                traffic = json.load(open(tpath)).get("bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic = tj.get("bytes_per_launch")
+                traffic_source = (f"not measured in this run: PMC passes (TCC FETCH_SIZE x2 + WRITE_SIZE) of this same "
+                                  f"command kept in profiles/hbm_traffic.json, collected {tj.get('collected', 'date unknown')}")
             except Exception:
                 traffic = None
         line = {
@@ -289,7 +339,9 @@ def main():
             "pct_hbm_peak": round(100.0 * value / (HBM_PEAK_GBS * world), 2),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_source": traffic_source,
                          "kernel": "k_crc_batch", "avg_launch_ms": round(avg_ms, 4),
+                         "median_launch_ms": round(median_ms, 4),
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -149,10 +149,13 @@ int tcrc_dev_extend_long(tcrc_ctx* ctx, const void* d_base, const tcrc_desc* h_d
  * with these limits: at most 64 buffers per call (TCRC_ERR_TOO_LARGE beyond), each up to 1 GiB.  The
  * call only enqueues two kernels (one clears the lines) on `stream`: it allocates nothing, issues no copy
  * command and does not synchronise, so d_out is complete once the stream has run (the caller synchronises).
- * The partial results live in 8 KiB of the library's static device memory (each GPU holds its own copy
- * for the life of the process; the same array holds the 272 KiB of power tables built at tcrc_init).
- * Every call on a GPU shares those 8 KiB: calls that overlap on one GPU - different streams without an
- * event between them, different contexts, different threads - race and give wrong values. */
+ * The partial results live in the library's static device memory (each GPU holds its own copy for the life
+ * of the process: 64 KiB of accumulator lines in eight slices of 8 KiB, and the 272 KiB of power tables built
+ * at tcrc_init).  Every context takes one slice at tcrc_init - the least used one, so up to eight contexts
+ * on a GPU have lines of their own and their calls may overlap freely.  Calls of ONE context (or of
+ * contexts that share a slice, from the ninth context of a GPU on) share its 8 KiB: if they overlap -
+ * different streams without an event between them, different threads - they race and give wrong values;
+ * keep a context's calls on one stream, or order them with events. */
 int tcrc_dev_extend_long_noalloc(tcrc_ctx* ctx, const void* d_base, const tcrc_desc* h_desc, uint64_t n,
                                  uint32_t segment_len, uint32_t* d_out, void* stream);
 

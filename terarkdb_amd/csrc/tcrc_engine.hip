@@ -1445,6 +1445,7 @@ int tcrc_debug_tables(int lanes, uint32_t* main_out, uint32_t* aux_out, size_t a
 int tcrc_shutdown(tcrc_ctx* ctx) {
   if (!ctx) return TCRC_OK;
   tcrc_internal::DeviceScope device_scope(ctx->device);
+  long_device_release(ctx);
   for (int gi = 0; gi < kGeoCount; ++gi) {
     if (ctx->d_tab_main[gi]) (void)hipFree(ctx->d_tab_main[gi]);
     if (ctx->d_tab_aux[gi]) (void)hipFree(ctx->d_tab_aux[gi]);

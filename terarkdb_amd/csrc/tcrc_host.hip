@@ -305,7 +305,8 @@ int tcrc_host_batch_stamp(tcrc_ctx* ctx, const void* h_base, uint64_t base_bytes
   if (int rc = host_begin(L)) return rc;
   StreamGuard guard(L->stream);  // an error return must not leave copies from the caller's memory in flight
   if (wants_long_route(h_desc, n, h_suffix)) {
-    if (int rc = check_flags_host(flags, TCRC_F_MASK)) return rc;
+    // (the four-lanes hint says nothing on this route: every buffer is cut into segments anyway)
+    if (int rc = check_flags_host(flags, TCRC_F_MASK | TCRC_F_SHORT_SPANS)) return rc;
     if (int rc = long_route(ctx, L, h_base, base_bytes, h_desc, n, h_out)) return rc;
     guard.dismiss();  // long_route returns with the kernel's results complete: the copies ahead of it have finished
     if (flags & TCRC_F_MASK)
@@ -398,7 +399,8 @@ int tcrc_host_batch_verify(tcrc_ctx* ctx, const void* h_base, uint64_t base_byte
   if (int rc = host_begin(L)) return rc;
   StreamGuard guard(L->stream);  // an error return must not leave copies from the caller's memory in flight
   if (wants_long_route(h_desc, n, h_suffix)) {
-    if (int rc = check_flags_host(flags, TCRC_F_MASK | TCRC_F_EXPECT_AFTER | TCRC_F_EXPECT_BEFORE)) return rc;
+    if (int rc = check_flags_host(flags, TCRC_F_MASK | TCRC_F_EXPECT_AFTER | TCRC_F_EXPECT_BEFORE | TCRC_F_SHORT_SPANS))
+      return rc;
     if (!h_expected && !(flags & (TCRC_F_EXPECT_AFTER | TCRC_F_EXPECT_BEFORE)))
       return fail(TCRC_ERR_INVALID, "verify needs h_expected or an in-image expectation flag");
     std::vector<uint32_t> crc(n);

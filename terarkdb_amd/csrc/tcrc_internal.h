@@ -206,6 +206,8 @@ int run_segments(tcrc_ctx* ctx, BatchParams p, const LongArgs& la, void* stream)
 int run_wal_scan(tcrc_ctx* ctx, WalScanParams p, void* stream);
 // Per-device set-up of the long-buffer path at tcrc_init (the context's GPU is current): the power tables.
 int long_device_setup(tcrc_ctx* ctx);
+// Gives the context's slice of the static accumulator lines back (tcrc_shutdown).
+void long_device_release(tcrc_ctx* ctx);
 
 // Makes the context's GPU the calling thread's current device for the rest of the scope and puts the
 // caller's device back afterwards (a multi-GPU host must not find its current device changed by a call).
@@ -307,7 +309,8 @@ struct tcrc_ctx {
   std::mutex long_mu;
   tcrc_scratch long_in, long_acc;
   const uint32_t* d_pow = nullptr;  // kPowTables x kPowEntries words on this GPU (shared by its contexts, never freed)
-  uint32_t* d_static = nullptr;     // this GPU's copy of the library's static scratch (accumulator lines first)
+  uint32_t* d_static = nullptr;     // the context's slice of the accumulator lines in this GPU's copy of the library's static scratch
+  int static_slice = -1;            // which slice (long_device_setup)
   uint32_t* long_flag = nullptr;    // pinned word the long-buffer kernel writes its completion to (long_mu)
   uint32_t long_seq = 0;
   bool poll_completion = true;      // TCRC_NO_POLL=1: always hipStreamSynchronize (for comparison)

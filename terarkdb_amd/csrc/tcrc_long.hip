@@ -34,7 +34,12 @@ namespace {
 // ---- static device memory -------------------------------------------------------------------
 // [accumulator lines of the entry point that allocates nothing | power tables T_8 .. T_41]
 // Every GPU the library runs on holds its own copy (at its own address) until the process ends.
-constexpr uint32_t kStaticAccWords = (uint32_t)kLongInline * 32u;  // one 128-byte line per buffer
+// The accumulator lines come in kStaticSlices slices of kLongInline lines: every context of a GPU takes a
+// slice of its own at tcrc_init (the ninth and later contexts share with earlier ones), so that calls of
+// different contexts do not meet in the same lines.
+constexpr uint32_t kStaticSlices = 8;
+constexpr uint32_t kSliceWords = (uint32_t)kLongInline * 32u;  // one 128-byte line per buffer
+constexpr uint32_t kStaticAccWords = kStaticSlices * kSliceWords;
 constexpr uint32_t kStaticPowWords = (uint32_t)kPowTables * (uint32_t)kPowEntries;
 constexpr uint32_t kStaticWords = kStaticAccWords + kStaticPowWords;
 static __device__ __align__(256) uint32_t scratch[kStaticWords];
@@ -42,6 +47,7 @@ static __device__ __align__(256) uint32_t scratch[kStaticWords];
 constexpr int kMaxDevices = 64;
 std::mutex g_static_mu;
 uint32_t* g_static_ptr[kMaxDevices] = {};  // device address of `scratch` on every GPU set up so far
+uint32_t g_slice_users[kMaxDevices][kStaticSlices] = {};  // contexts holding each slice (guarded by g_static_mu)
 
 // T_s[i] = x^(8 * 2^s * i) mod P for s = kPowMinShift + blockIdx.x, i < kPowEntries.
 __global__ __launch_bounds__(1024) void k_pow_tables(uint32_t* tables) {
@@ -107,15 +113,37 @@ int long_device_setup(tcrc_ctx* ctx) {
     uint32_t* ptr = nullptr;
     HIP_TRY(hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch)));
     if (!ptr) return fail(TCRC_ERR_HIP, "hipGetSymbolAddress returned no address for the static scratch");
-    HIP_TRY(hipMemsetAsync(ptr, 0, (size_t)kStaticAccWords * 4, nullptr));
-    hipLaunchKernelGGL(k_pow_tables, dim3(kPowTables), dim3(1024), 0, nullptr, ptr + kStaticAccWords);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(nullptr));
+    // on a stream of its own, not the legacy default stream: work on that one would end a stream capture
+    // another thread has open in global mode, and serialises against every blocking stream
+    hipStream_t s = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(256), 0, s, ptr, kStaticAccWords);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(k_pow_tables, dim3(kPowTables), dim3(1024), 0, s, ptr + kStaticAccWords);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipStreamDestroy(s);
+    HIP_TRY(e);
     g_static_ptr[ctx->device] = ptr;
   }
-  ctx->d_static = g_static_ptr[ctx->device];
-  ctx->d_pow = ctx->d_static + kStaticAccWords;
+  // the least used slice of accumulator lines
+  uint32_t best = 0;
+  for (uint32_t i = 1; i < kStaticSlices; ++i)
+    if (g_slice_users[ctx->device][i] < g_slice_users[ctx->device][best]) best = i;
+  ++g_slice_users[ctx->device][best];
+  ctx->static_slice = (int)best;
+  ctx->d_static = g_static_ptr[ctx->device] + (size_t)best * kSliceWords;
+  ctx->d_pow = g_static_ptr[ctx->device] + kStaticAccWords;
   return TCRC_OK;
+}
+
+void long_device_release(tcrc_ctx* ctx) {
+  if (ctx->static_slice < 0 || ctx->device < 0 || ctx->device >= kMaxDevices) return;
+  std::lock_guard<std::mutex> lock(g_static_mu);
+  if (g_slice_users[ctx->device][ctx->static_slice]) --g_slice_users[ctx->device][ctx->static_slice];
+  ctx->static_slice = -1;
 }
 
 }  // namespace tcrc_internal
@@ -161,7 +189,8 @@ int acc_reserve(tcrc_ctx* ctx, hipStream_t s) {
   const size_t bytes = ((size_t)kLongLdsBuffers + 1) * 128;
   if (ctx->long_acc.bytes >= bytes) return TCRC_OK;
   if (int rc = scratch_reserve(ctx, &ctx->long_acc, bytes)) return rc;
-  HIP_TRY(hipMemsetAsync(ctx->long_acc.p, 0, ctx->long_acc.bytes, s));
+  hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(256), 0, s, (uint32_t*)ctx->long_acc.p, (uint32_t)(ctx->long_acc.bytes / 4));
+  HIP_TRY(hipGetLastError());
   return TCRC_OK;
 }
 
@@ -288,7 +317,7 @@ extern "C" int tcrc_dev_extend_long_noalloc(tcrc_ctx* ctx, const void* d_base, c
   ctx->st_long_bytes.fetch_add(total, std::memory_order_relaxed);
   hipStream_t s = (hipStream_t)stream;
   // the lines keep whatever an earlier call (or one that was cut short) left in them
-  hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(256), 0, s, ctx->d_static, kStaticAccWords);
+  hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(256), 0, s, ctx->d_static, kSliceWords);
   HIP_TRY(hipGetLastError());
   la.acc = ctx->d_static;
   BatchParams p{};

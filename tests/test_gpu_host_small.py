@@ -214,3 +214,37 @@ def test_few_buffers_some_of_them_long(eng):
                                     expected.ctypes.data, None, None, counts) == capi.ERR_INVALID
     assert L.tcrc_host_batch_verify(eng.ctx, img.ctypes.data, total, d0, n, None, 0, None, None, None,
                                     counts) == capi.ERR_INVALID
+
+
+def test_short_span_hint_with_one_long_buffer(eng):
+    """TCRC_F_SHORT_SPANS is a hint: a table's short data blocks plus one large filter or index block (which sends
+    the call down the long-buffer route) must give the same values and verdicts with and without it."""
+    import terarkdb_amd.capi as capi
+    L = capi.lib
+    lens = [700, 1100, 90000, 333, 0, 1408, 262144 + 7]
+    total = sum(lens) + 5 * len(lens) + 64
+    img = O.splitmix(total + 8 - total % 8, 78)[:total].copy()
+    offs, pos = [], 7
+    for ln in lens:
+        offs.append(pos)
+        pos += ln + 5
+    n = len(lens)
+    d = _descs(offs, lens, [0] * n)
+    want = O.batch_extend(img, np.array(offs, dtype=np.uint64), np.array(lens, dtype=np.uint32), None, None, True)
+    for hint in (0, capi.F_SHORT_SPANS):
+        out = (C.c_uint32 * n)()
+        assert L.tcrc_host_batch_stamp(eng.ctx, img.ctypes.data, total, d, n, None, capi.F_MASK | hint, out) == 0, \
+            capi.lib.tcrc_last_error().decode()
+        assert (np.frombuffer(out, dtype=np.uint32) == want).all()
+    for o, ln, w in zip(offs, lens, want):
+        img[o + ln:o + ln + 4] = np.frombuffer(int(w).to_bytes(4, "little"), dtype=np.uint8)
+    img[offs[2] + 4242] ^= 0x10
+    for hint in (0, capi.F_SHORT_SPANS):
+        counts = (C.c_uint64 * 3)()
+        ok = np.full(n, 9, dtype=np.uint8)
+        got = np.zeros(n, dtype=np.uint32)
+        rc = L.tcrc_host_batch_verify(eng.ctx, img.ctypes.data, total, d, n, None, capi.F_EXPECT_AFTER | hint, None,
+                                      got.ctypes.data, ok.ctypes.data, counts)
+        assert rc == 0, capi.lib.tcrc_last_error().decode()
+        assert list(counts) == [1, 2, n] and ok.tolist() == [1, 1, 0, 1, 1, 1, 1]
+        assert (np.delete(got, 2) == np.delete(want, 2)).all()

@@ -103,3 +103,38 @@ def test_entry_point_is_captured_into_a_graph_and_replayed():
     want2 = O.batch_extend(host2, np.array(offs, np.uint64), np.array(lens, np.uint32), np.array(inits, np.uint32))
     assert (out.cpu().numpy().view(np.uint32) == want2).all()
     eng.close()
+
+
+def test_two_contexts_one_after_the_other_and_side_by_side():
+    """Two contexts on one GPU have accumulator lines of their own: calls made strictly one after the other give
+    the right values, and so do calls of the two contexts that overlap on two streams."""
+    import gpu_util as G
+    a, b = G.engine(), G.engine()
+    host = O.splitmix(64 << 20, 4242)
+    dev = G.to_dev(host)
+    offs = [i * (1 << 20) + (i % 7) for i in range(48)]
+    lens = [(1 << 20) - 64 + 3 * i for i in range(48)]
+    inits = [(i * 2654435761) & 0xffffffff for i in range(48)]
+    want = O.batch_extend(host, np.array(offs, np.uint64), np.array(lens, np.uint32), np.array(inits, np.uint32))
+    oa = torch.zeros(48, dtype=torch.int32, device="cuda")
+    ob = torch.zeros(48, dtype=torch.int32, device="cuda")
+    # one after the other
+    for e, o in ((a, oa), (b, ob), (a, oa)):
+        o.zero_()
+        e.extend_long(dev, offs, lens, inits, o, noalloc=True)
+        torch.cuda.synchronize()
+        assert (o.cpu().numpy().view(np.uint32) == want).all()
+    # side by side: two streams, nothing between the calls
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for rep in range(20):
+        oa.zero_()
+        ob.zero_()
+        torch.cuda.synchronize()
+        a.extend_long(dev, offs, lens, inits, oa, noalloc=True, stream=sa.cuda_stream)
+        b.extend_long(dev, offs[::-1], lens[::-1], inits[::-1], ob, noalloc=True, stream=sb.cuda_stream)
+        torch.cuda.synchronize()
+        assert (oa.cpu().numpy().view(np.uint32) == want).all(), rep
+        assert (ob.cpu().numpy().view(np.uint32) == want[::-1]).all(), rep
+    a.close()
+    b.close()

@@ -10,8 +10,8 @@ rm -rf $O && mkdir -p $O
 set -e
 timeout -k 10 300 python3 -u bench.py > $O/bench.json 2> $O/bench.err
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python3 bench.py --no-cpu-baseline > $O/kt.log 2>&1
-timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE -d $O/fetch -o fetch -- python3 bench.py --no-cpu-baseline --steps 5 > $O/fetch.log 2>&1
-timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE -d $O/write -o wr -- python3 bench.py --no-cpu-baseline --steps 5 > $O/write.log 2>&1
+timeout -k 10 120 rocprofv3 --pmc FETCH_SIZE -d $O/fetch -o fetch -- python3 bench.py --no-cpu-baseline --steps 5 > $O/fetch.log 2>&1
+timeout -k 10 120 rocprofv3 --pmc WRITE_SIZE -d $O/write -o wr -- python3 bench.py --no-cpu-baseline --steps 5 > $O/write.log 2>&1
 python3 tools/rocprof_summary.py kernel $O/kt/kt_results.db $O/bench_kernel_stats.csv > /dev/null
 python3 tools/rocprof_summary.py pmc $O/fetch/fetch_results.db $O/write/wr_results.db k_crc_batch $O/hbm_traffic.json > /dev/null
 rm -rf $O/kt $O/fetch $O/write
@@ -27,8 +27,8 @@ for spec in log_2k:k_wal_fused: log_mixed:k_wal_fused: log_mixed_recyclable:k_wa
   only=${name%_verify}; only=${only%_stamp}
   timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/kt_$name -o kt -- python3 tools/measure_configs.py --only $only $extra --launches 30 --settle 1.0 > $O/kt_$name.log 2>&1
   python3 tools/rocprof_summary.py kernel $O/kt_$name/kt_results.db $O/${name}_kernel_stats.csv > /dev/null
-  timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE -d $O/f_$name -o fetch -- python3 tools/measure_configs.py --only $only $extra --launches 5 --settle 0.2 > $O/f_$name.log 2>&1
-  timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE -d $O/w_$name -o wr -- python3 tools/measure_configs.py --only $only $extra --launches 5 --settle 0.2 > $O/w_$name.log 2>&1
+  timeout -k 10 120 rocprofv3 --pmc FETCH_SIZE -d $O/f_$name -o fetch -- python3 tools/measure_configs.py --only $only $extra --launches 5 --settle 0.2 > $O/f_$name.log 2>&1
+  timeout -k 10 120 rocprofv3 --pmc WRITE_SIZE -d $O/w_$name -o wr -- python3 tools/measure_configs.py --only $only $extra --launches 5 --settle 0.2 > $O/w_$name.log 2>&1
   python3 tools/rocprof_summary.py pmc $O/f_$name/fetch_results.db $O/w_$name/wr_results.db $needle $O/${name}_hbm_traffic.json > /dev/null
   rm -rf $O/kt_$name $O/f_$name $O/w_$name
   echo "$name done"

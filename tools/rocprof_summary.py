@@ -5,6 +5,7 @@ usage: rocprof_summary.py kernel <kt_results.db> <out.csv>
        rocprof_summary.py pmc <fetch_results.db> <write_results.db> <kernel-substring> <out.json>
        rocprof_summary.py sq <results.db> <kernel-substring> <out.json>
 """
+import datetime
 import json
 import sqlite3
 import sys
@@ -37,6 +38,7 @@ def pmc(fetch_db, write_db, needle, out):
     write_bytes = w_kb * 1024.0
     res = {
         "kernel": needle,
+        "collected": datetime.date.today().isoformat(),
         "fetch_size_kib_avg": f_kb, "fetch_dispatches": f_n,
         "write_size_kib_avg": w_kb, "write_dispatches": w_n,
         "read_bytes_per_launch": read_bytes, "write_bytes_per_launch": write_bytes,
