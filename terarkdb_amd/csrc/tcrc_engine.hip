@@ -1401,6 +1401,7 @@ int tcrc_init(int device, tcrc_ctx** out) {
   }
   if (const char* e = getenv("TCRC_NONTEMPORAL")) ctx->nontemporal = atoi(e) != 0;
   if (const char* e = getenv("TCRC_NO_POLL")) ctx->poll_completion = atoi(e) == 0;
+  if (const char* e = getenv("TCRC_DEBUG_NOALLOC_MEMSET")) ctx->debug_noalloc_memset = atoi(e) != 0;
   for (int gi = 0; gi < kGeoCount; ++gi) {
     const int G = kGeoLanes[gi];
     int log2g = 0;

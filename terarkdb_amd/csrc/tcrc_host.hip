@@ -80,6 +80,7 @@ int lane_signal(tcrc_ctx* ctx, tcrc_lane* L, DoneSignal* d) {  // after zc_begin
   if (!ctx->poll_completion) return TCRC_OK;
   if (!L->done_counter) {
     HIP_TRY(hipMalloc((void**)&L->done_counter, 128));
+    // (the lane's own stream: never under a caller's graph capture, where a memset node does not replay right)
     HIP_TRY(hipMemsetAsync(L->done_counter, 0, 128, L->stream));
   }
   if (++L->done_seq == 0) ++L->done_seq;

@@ -311,6 +311,7 @@ struct tcrc_ctx {
   const uint32_t* d_pow = nullptr;  // kPowTables x kPowEntries words on this GPU (shared by its contexts, never freed)
   uint32_t* d_static = nullptr;     // the context's slice of the accumulator lines in this GPU's copy of the library's static scratch
   int static_slice = -1;            // which slice (long_device_setup)
+  bool debug_noalloc_memset = false;  // TCRC_DEBUG_NOALLOC_MEMSET=1: clear the lines with hipMemsetAsync (development aid)
   uint32_t* long_flag = nullptr;    // pinned word the long-buffer kernel writes its completion to (long_mu)
   uint32_t long_seq = 0;
   bool poll_completion = true;      // TCRC_NO_POLL=1: always hipStreamSynchronize (for comparison)

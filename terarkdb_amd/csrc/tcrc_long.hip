@@ -64,11 +64,11 @@ __global__ __launch_bounds__(1024) void k_pow_tables(uint32_t* tables) {
   }
 }
 
-// Zeroes `words` dwords.  The entry point that allocates nothing clears its accumulator lines with this kernel
-// and not with hipMemsetAsync: with the memset recorded into a HIP graph in front of the kernel, only the first
-// launch of the graph wrote its results (ROCm 7.2; from the second launch on d_out was left as it was, which
-// is what lines cleared under the kernel's arrivals look like).  With a kernel doing the clearing every launch
-// of the graph writes them.
+// Zeroes `words` dwords.  The library clears device words that a caller's stream may find under graph capture with
+// this kernel and never with hipMemsetAsync: recorded into a HIP graph, the memset node fills zeros on the graph's
+// first launch only - from the second launch on it writes a 16-byte pattern of stale words (ROCm 7.2; the fill
+// runs in its place in front of the next kernel, its value is what is wrong), so the accumulator lines held
+// garbage, no buffer's arrival count reached its total and no result was written.
 __global__ __launch_bounds__(256) void k_zero_words(uint32_t* p, uint32_t words) {
   for (uint32_t i = threadIdx.x; i < words; i += 256u) p[i] = 0u;
 }
@@ -317,12 +317,29 @@ extern "C" int tcrc_dev_extend_long_noalloc(tcrc_ctx* ctx, const void* d_base, c
   ctx->st_long_bytes.fetch_add(total, std::memory_order_relaxed);
   hipStream_t s = (hipStream_t)stream;
   // the lines keep whatever an earlier call (or one that was cut short) left in them
-  hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(256), 0, s, ctx->d_static, kSliceWords);
-  HIP_TRY(hipGetLastError());
+  if (ctx->debug_noalloc_memset) {
+    // development aid (TCRC_DEBUG_NOALLOC_MEMSET=1): the form that went wrong under graph replay, kept so that
+    // a trace of it can be taken
+    HIP_TRY(hipMemsetAsync(ctx->d_static, 0, (size_t)kSliceWords * 4, s));
+  } else {
+    hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(256), 0, s, ctx->d_static, kSliceWords);
+    HIP_TRY(hipGetLastError());
+  }
   la.acc = ctx->d_static;
   BatchParams p{};
   p.base = (const uint8_t*)d_base;
   p.out = d_out;
   p.n = nseg;
   return run_segments(ctx, p, la, stream);
+}
+
+// Development aid (not part of the C ABI in include/): copies the first `words` dwords of the context's slice of
+// the static accumulator lines to the host, after waiting for the device.
+extern "C" int tcrc_debug_static_lines(tcrc_ctx* ctx, uint32_t* h_out, size_t words) {
+  if (!ctx || !h_out || !ctx->d_static) return fail(TCRC_ERR_INVALID, "null argument");
+  if (words > kSliceWords) words = kSliceWords;
+  TCRC_DEVICE_SCOPE(ctx);
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(h_out, ctx->d_static, words * 4, hipMemcpyDeviceToHost));
+  return TCRC_OK;
 }
