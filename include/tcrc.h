@@ -223,17 +223,37 @@ int tcrc_dev_wal_list(tcrc_ctx* ctx, const void* d_img, uint64_t size, uint64_t 
  * way n calls of log::Writer::AddRecord append them (db/log_writer.cc:45-151): fragments that never
  * cross a 32 KiB block, 7-byte headers (11 with the log number when recycle != 0), zero-filled block
  * tails shorter than a header, and Mask(crc32c(type | [log number] | payload)) in every header.
+ * ONE kernel: every payload byte is read once, stored to its place in the image and folded into its
+ * fragment's checksum from the same registers; where the headers go is planned on the host from the
+ * record lengths alone.
  * Record i is the h_recs[i].len bytes at d_src + h_recs[i].offset (h_recs[i].init is ignored).
  * block_offset is the position inside the current 32 KiB block at which the image continues an
  * existing log (0 for a new file); *block_offset_out (may be NULL) is that position after the call
  * (always below 32768: 0 when the image ends exactly at a block boundary), ready to be passed to the next call.
  * *h_written receives the image size; tcrc_wal_framed_size gives it beforehand.  d_dst must not
- * overlap d_src.  Returns with the image complete. */
+ * overlap d_src.  Returns with the image complete (plan, enqueue, wait for the stream). */
 int tcrc_dev_wal_frame(tcrc_ctx* ctx, const void* d_src, const tcrc_desc* h_recs, uint64_t n, uint64_t log_number,
                        int recycle, uint32_t block_offset, void* d_dst, uint64_t dst_capacity, uint64_t* h_written,
                        uint32_t* block_offset_out, uint64_t* h_physical_records, void* stream);
 /* Bytes tcrc_dev_wal_frame will write for these records (host arithmetic on the lengths only). */
 uint64_t tcrc_wal_framed_size(const tcrc_desc* h_recs, uint64_t n, int recycle, uint32_t block_offset);
+
+/* The same in two steps, for a writer that keeps the GPU busy: the plan is host work (the loop of
+ * db/log_writer.cc:45-100 over the record lengths; its piece list goes to the device on a stream of the
+ * context's own), the enqueue is one kernel launch on the caller's stream and waits for nothing - so a group
+ * commit can plan batch k+1 while batch k is being framed.  A plan fixes the record lengths and source offsets,
+ * the header kind, the log number and the starting block offset; it can be enqueued any number of times (other
+ * source bytes at the same offsets, other destinations).  The image is complete once the stream has run.
+ * tcrc_wal_plan_free waits for the launches that read the plan.  Limits: source offsets and the image below 1 TiB. */
+typedef struct tcrc_wal_plan tcrc_wal_plan;
+int tcrc_wal_plan_create(tcrc_ctx* ctx, const tcrc_desc* h_recs, uint64_t n, uint64_t log_number, int recycle,
+                         uint32_t block_offset, tcrc_wal_plan** out);
+uint64_t tcrc_wal_plan_image_bytes(const tcrc_wal_plan* plan);       /* what tcrc_wal_framed_size gives */
+uint32_t tcrc_wal_plan_block_offset(const tcrc_wal_plan* plan);      /* block offset after the image */
+uint64_t tcrc_wal_plan_physical_records(const tcrc_wal_plan* plan);  /* headers the image holds */
+int tcrc_dev_wal_frame_enqueue(tcrc_ctx* ctx, tcrc_wal_plan* plan, const void* d_src, void* d_dst,
+                               uint64_t dst_capacity, void* stream);
+void tcrc_wal_plan_free(tcrc_wal_plan* plan);
 
 /* Sets d_counts to {0, ~0, 0}. */
 int tcrc_dev_counts_reset(tcrc_ctx* ctx, uint64_t* d_counts, void* stream);

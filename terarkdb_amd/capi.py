@@ -75,6 +75,12 @@ SIGNATURES.update({
     "tcrc_dev_wal_frame": (_i, [_vp, _vp, _vp, _u64, _u64, _i, _u32, _vp, _u64, C.POINTER(_u64), C.POINTER(_u32),
                                 C.POINTER(_u64), _vp]),
     "tcrc_wal_framed_size": (_u64, [_vp, _u64, _i, _u32]),
+    "tcrc_wal_plan_create": (_i, [_vp, _vp, _u64, _u64, _i, _u32, C.POINTER(_vp)]),
+    "tcrc_wal_plan_free": (None, [_vp]),
+    "tcrc_wal_plan_image_bytes": (_u64, [_vp]),
+    "tcrc_wal_plan_block_offset": (_u32, [_vp]),
+    "tcrc_wal_plan_physical_records": (_u64, [_vp]),
+    "tcrc_dev_wal_frame_enqueue": (_i, [_vp, _vp, _vp, _vp, _u64, _vp]),
     "tcrc_dev_wal_list": (_i, [_vp, _vp, _u64, _u64, _vp, _vp, _u64, C.POINTER(_u64), _vp]),
     "tcrc_host_wal_list": (_i, [_vp, _vp, _u64, _u64, _vp, _vp, _u64, C.POINTER(_u64)]),
     "tcrc_get_stats": (_i, [_vp, C.POINTER(Stats)]),
@@ -222,6 +228,22 @@ class Engine:
                                      dst.numel(), C.byref(written), C.byref(bo), C.byref(phys), self._stream(stream)))
         return written.value, bo.value, phys.value
 
+    def wal_plan(self, offsets, lens, log_number, recycle, block_offset=0):
+        """Plans the framing of the records (offsets[i], lens[i]) - host arithmetic only, plus the upload of the
+        plan; returns a WalPlan to hand to wal_frame_enqueue any number of times, and to close()."""
+        n = len(offsets)
+        arr = (Desc * max(n, 1))()
+        for i in range(n):
+            arr[i].offset, arr[i].len, arr[i].init = int(offsets[i]), int(lens[i]), 0
+        h = C.c_void_p()
+        check(lib.tcrc_wal_plan_create(self.ctx, arr, n, log_number, int(recycle), block_offset, C.byref(h)))
+        return WalPlan(h)
+
+    def wal_frame_enqueue(self, plan, src, dst, stream=None):
+        """Enqueues the framing kernel of `plan` on the stream: src -> dst (device uint8 tensors).  Nothing is
+        waited for; the image is complete once the stream has run."""
+        check(lib.tcrc_dev_wal_frame_enqueue(self.ctx, plan.handle, _dp(src), _dp(dst), dst.numel(), self._stream(stream)))
+
     def wal_list(self, img, size, log_number, blocks, records, capacity, stream=None):
         """records: uint8 device tensor of 16 * capacity bytes (tcrc_wal_record); returns the total count."""
         n = C.c_uint64(0)
@@ -257,6 +279,22 @@ class Engine:
 
     def counts_reset(self, counts, stream=None):
         check(lib.tcrc_dev_counts_reset(self.ctx, _dp(counts), self._stream(stream)))
+
+
+class WalPlan:
+    """A framing plan (tcrc_wal_plan): image size, block offset afterwards and physical record count are known
+    as soon as it exists."""
+
+    def __init__(self, handle):
+        self.handle = handle
+        self.image_bytes = lib.tcrc_wal_plan_image_bytes(handle)
+        self.block_offset = lib.tcrc_wal_plan_block_offset(handle)
+        self.physical_records = lib.tcrc_wal_plan_physical_records(handle)
+
+    def close(self):
+        if self.handle:
+            lib.tcrc_wal_plan_free(self.handle)
+            self.handle = C.c_void_p()
 
 
 def make_desc_tensor(offsets, lens, inits, device):

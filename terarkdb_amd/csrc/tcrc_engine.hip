@@ -71,6 +71,17 @@ __device__ __forceinline__ uint4 load16(const uint8_t* p) {
   return make_uint4(v.x, v.y, v.z, v.w);
 }
 
+// 16 bytes to any address: one global_store_dwordx4.
+typedef v4u_any __attribute__((address_space(1)))* gptr16w;
+__device__ __forceinline__ void store16(uint8_t* p, const uint4& v) {
+  v4u x;
+  x.x = v.x;
+  x.y = v.y;
+  x.z = v.z;
+  x.w = v.w;
+  *(gptr16w)p = x;
+}
+
 // Z_D via the replicated tables.  LDS layout of the main set (128 KiB): entry b of the pair (T0, T1) is the 256
 // bytes at b * 256 - 32 replicas of T0[b], then 32 replicas of T1[b] - and the pair (T2, T3) follows at 64 KiB
 // in the same form.  The byte address of a lookup is then (state byte << 8) | (lane mod 32) * 4 | region bit 16,
@@ -103,9 +114,14 @@ template <int G> struct AuxDwords {
   static constexpr int value = (1 + Geo<G>::kLog2) * 1024 + 16 * G * (G <= 16 ? 4 : 1);
 };
 
-template <int G, bool NT>
+// COPY: the bytes are also written to [dstp, dstp + len) as they pass through the registers (log framing: the
+// payload is read once, copied and checksummed); lane groups without rows store to `sink` (4 KiB of writable
+// scratch) where the others store rows.  PHASE_DST: the rows are aligned to the DESTINATION's 128-byte lines
+// instead of the source's, so that the stores are the aligned ones and the loads take whatever alignment is left.
+template <int G, bool NT, bool COPY = false, bool PHASE_DST = false>
 __device__ __forceinline__ uint32_t span_remainder(const uint32_t* lds, uint32_t LB, int lane, const uint8_t* ptr,
-                                                   uint32_t len, uint32_t init, bool valid, const uint8_t* safe) {
+                                                   uint32_t len, uint32_t init, bool valid, const uint8_t* safe,
+                                                   uint8_t* dstp = nullptr, uint8_t* sink = nullptr) {
   constexpr int D = 16 * G;
   constexpr int LOG2G = Geo<G>::kLog2;
   // lanes of a group that share the un-shift multiplication (a whole wave per buffer keeps it on one lane:
@@ -121,7 +137,8 @@ __device__ __forceinline__ uint32_t span_remainder(const uint32_t* lds, uint32_t
   // the last row after it are read (same lines as message bytes) and masked to zero: leading
   // zeros leave a CRC remainder unchanged, the `tpad` trailing ones are undone after the
   // reduction by one multiplication with x^(-8 tpad).
-  const uint32_t a0 = live ? (uint32_t)((uintptr_t)ptr & (uintptr_t)(D - 1)) : 0u;
+  const uintptr_t phase_of = (COPY && PHASE_DST) ? (uintptr_t)dstp : (uintptr_t)ptr;
+  const uint32_t a0 = live ? (uint32_t)(phase_of & (uintptr_t)(D - 1)) : 0u;
   const uint32_t span = a0 + elen;
   const uint32_t R = (span + D - 1) / D;
   const uint32_t tpad = R * D - span;
@@ -153,12 +170,51 @@ __device__ __forceinline__ uint32_t span_remainder(const uint32_t* lds, uint32_t
     // default cache policy, not the streaming one of the whole rows: the line a span starts or ends in is
     // usually also the line its neighbour ends or starts in, and is wanted again within microseconds
     // (4 KiB blocks packed end to end: 6.7 TB/s against 6.2 with streaming loads here too)
+    if constexpr (COPY && PHASE_DST) {
+      // Rows follow the destination's lines here, so a column that sticks out of the message would be read from
+      // bytes that are not in the message's lines at all (before the source allocation, or past its end).  Such
+      // a column is read from the nearest sixteen bytes INSIDE the message instead and shifted into place; what
+      // is shifted in is zero, which is what the trimming makes of those bytes anyway.
+      if (live && m > -16 && m < (int)elen) {
+        const int mc = m < 0 ? 0 : (m + 16 > (int)elen ? (int)elen - 16 : m);
+        v = load16<false>(ptr + mc);
+        const int sh = mc - m;  // > 0: column byte k is loaded byte k - sh; < 0: loaded byte k + |sh|
+        if (sh != 0) {
+          unsigned long long lo = ((unsigned long long)v.y << 32) | v.x;
+          unsigned long long hi = ((unsigned long long)v.w << 32) | v.z;
+          if (sh > 0) {
+            const uint32_t b = 8u * (uint32_t)sh;
+            if (b >= 64u) {
+              hi = lo << (b - 64u);
+              lo = 0;
+            } else {
+              hi = (hi << b) | (lo >> (64u - b));
+              lo <<= b;
+            }
+          } else {
+            const uint32_t b = 8u * (uint32_t)(-sh);
+            if (b >= 64u) {
+              lo = hi >> (b - 64u);
+              hi = 0;
+            } else {
+              lo = (lo >> b) | (hi << (64u - b));
+              hi >>= b;
+            }
+          }
+          v = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+        }
+      }
+      return v;
+    }
     if (live && m > -16 && m < (int)elen) v = load16<false>(ptr + m);
     return v;
   };
   // ... and trimmed to the message, with the initial register folded into message bytes 0..3.
   auto fold_checked = [&](uint4 v, uint32_t r) {
     const int m = m0 + (int)(r * D);
+    if constexpr (COPY) {  // a column that lies wholly inside the message goes out as it came in
+      if (live && m >= 0 && m + 16 <= (int)elen) store16(dstp + m, v);
+    }
     if (live && m > -16 && m < (int)elen && (m < 4 || m + 16 > (int)elen)) {
       unsigned long long lo = ((unsigned long long)v.y << 32) | v.x;
       unsigned long long hi = ((unsigned long long)v.w << 32) | v.z;
@@ -197,6 +253,13 @@ __device__ __forceinline__ uint32_t span_remainder(const uint32_t* lds, uint32_t
     }
     fold_plain(v);
   };
+  // a row that is whole for every buffer of the wave
+  auto fold_whole = [&](const uint4& v, uint32_t r) {
+    if constexpr (COPY) {
+      if (live) store16(dstp + (m0 + (int)(r * D)), v);
+    }
+    fold_plain(v);
+  };
   // Rows go in bursts of four: four 16-byte loads per lane are issued back to back (512
   // contiguous bytes per buffer), then folded in order as they arrive.  Bursts without overlap
   // inside a wave measured faster than keeping loads in flight across the folds; the other
@@ -212,6 +275,13 @@ __device__ __forceinline__ uint32_t span_remainder(const uint32_t* lds, uint32_t
       const uint4 b = load16<NT>(q + D);
       const uint4 c = load16<NT>(q + 2 * D);
       const uint4 d = load16<NT>(q + 3 * D);
+      if constexpr (COPY) {
+        uint8_t* w = dstp + 16 * j;
+        store16(w, a);
+        store16(w + D, b);
+        store16(w + 2 * D, c);
+        store16(w + 3 * D, d);
+      }
       if (j == 0) a.x ^= r0;
       fold_plain(a);
       fold_plain(b);
@@ -224,6 +294,13 @@ __device__ __forceinline__ uint32_t span_remainder(const uint32_t* lds, uint32_t
       const uint4 b = load16<NT>(q + D);
       const uint4 c = load16<NT>(q + 2 * D);
       const uint4 d = load16<NT>(q + 3 * D);
+      if constexpr (COPY) {
+        uint8_t* w = dstp + 16 * j + (size_t)r * D;
+        store16(w, a);
+        store16(w + D, b);
+        store16(w + 2 * D, c);
+        store16(w + 3 * D, d);
+      }
       fold_plain(a);
       fold_plain(b);
       fold_plain(c);
@@ -257,15 +334,15 @@ __device__ __forceinline__ uint32_t span_remainder(const uint32_t* lds, uint32_t
         const uint4 b = cnt > 1u ? load_checked(x + 1u) : z;
         const uint4 c = cnt > 2u ? load_checked(x + 2u) : z;
         const uint4 d = cnt > 3u ? load_checked(x + 3u) : z;
-        if (x >= head_end && x < tail_begin) fold_plain(a); else fold_checked(a, x);
+        if (x >= head_end && x < tail_begin) fold_whole(a, x); else fold_checked(a, x);
         if (cnt > 1u) {
-          if (x + 1u >= head_end && x + 1u < tail_begin) fold_plain(b); else fold_checked(b, x + 1u);
+          if (x + 1u >= head_end && x + 1u < tail_begin) fold_whole(b, x + 1u); else fold_checked(b, x + 1u);
         }
         if (cnt > 2u) {
-          if (x + 2u >= head_end && x + 2u < tail_begin) fold_plain(c); else fold_checked(c, x + 2u);
+          if (x + 2u >= head_end && x + 2u < tail_begin) fold_whole(c, x + 2u); else fold_checked(c, x + 2u);
         }
         if (cnt > 3u) {
-          if (x + 3u >= head_end && x + 3u < tail_begin) fold_plain(d); else fold_checked(d, x + 3u);
+          if (x + 3u >= head_end && x + 3u < tail_begin) fold_whole(d, x + 3u); else fold_checked(d, x + 3u);
         }
       }
     };
@@ -284,16 +361,34 @@ __device__ __forceinline__ uint32_t span_remainder(const uint32_t* lds, uint32_t
       uint4 b = load16<NT>(q + D);
       uint4 c = load16<NT>(q + 2 * D);
       uint4 d = load16<NT>(q + 3 * D);
+      // COPY: where the window's rows go (lane groups that walk nothing write to the sink, branch-free like the loads)
+      uint8_t* w = nullptr;
+      uint32_t wstep = 0;
+      if constexpr (COPY) {
+        w = live ? dstp + (m0 + (int)(head_end * D)) : sink + 16 * lane;
+        wstep = qstep;
+      }
       for (uint32_t x = head_end + 4u; x < mid_end; x += 4u) {
         q += qstep;
+        if constexpr (COPY) store16(w, a);
         fold_plain(a);
         a = load16<NT>(q);
+        if constexpr (COPY) store16(w + D, b);
         fold_plain(b);
         b = load16<NT>(q + D);
+        if constexpr (COPY) store16(w + 2 * D, c);
         fold_plain(c);
         c = load16<NT>(q + 2 * D);
+        if constexpr (COPY) store16(w + 3 * D, d);
         fold_plain(d);
         d = load16<NT>(q + 3 * D);
+        if constexpr (COPY) w += wstep;
+      }
+      if constexpr (COPY) {
+        store16(w, a);
+        store16(w + D, b);
+        store16(w + 2 * D, c);
+        store16(w + 3 * D, d);
       }
       fold_plain(a);
       fold_plain(b);
@@ -312,13 +407,21 @@ __device__ __forceinline__ uint32_t span_remainder(const uint32_t* lds, uint32_t
       const uint4 b = left > 1u ? load16<NT>(q + qd) : z;
       const uint4 c = left > 2u ? load16<NT>(q + 2u * qd) : z;
       const uint4 d = load_checked(tail_begin);
-      if (left > 0u) fold_plain(a);
-      if (left > 1u) fold_plain(b);
-      if (left > 2u) fold_plain(c);
+      if (left > 0u) fold_whole(a, mid_end);
+      if (left > 1u) fold_whole(b, mid_end + 1u);
+      if (left > 2u) fold_whole(c, mid_end + 2u);
       fold_checked(d, tail_begin);
     }
   }
 
+  if constexpr (COPY) {
+    // The columns that stick out of the message at its two ends were not stored: the message's first and last
+    // sixteen bytes go out once more, whole (they overlap what the inner columns wrote with the same bytes).
+    if (live && j < 2) {
+      const uint32_t at = j == 0 ? 0u : elen - 16u;
+      store16(dstp + at, load16<false>(ptr + at));
+    }
+  }
   // Column states -> one value per lane (bytes j*16 .. j*16+15 of the last row).
   uint32_t u = fold_aux(aux, s0) ^ s1;
   u = fold_aux(aux, u) ^ s2;
@@ -355,7 +458,11 @@ __device__ __forceinline__ uint32_t span_remainder(const uint32_t* lds, uint32_t
   if (valid && !live && j == G - 1) {
     reg = r0;
     const uint32_t* T0 = aux + 768;  // one-byte step table
-    for (uint32_t k = 0; k < len; ++k) reg = T0[(reg ^ ptr[k]) & 0xffu] ^ (reg >> 8);
+    for (uint32_t k = 0; k < len; ++k) {
+      const uint8_t byte = ptr[k];
+      if constexpr (COPY) dstp[k] = byte;
+      reg = T0[(reg ^ byte) & 0xffu] ^ (reg >> 8);
+    }
   }
   return reg;
 }
@@ -1140,6 +1247,125 @@ __global__ __launch_bounds__(kThreads) void k_wal_fused(WalScanParams p) {
   }
 }
 
+
+// ---- log framing ---------------------------------------------------------------------------------------
+// One launch writes a log image the way log::Writer::AddRecord / EmitPhysicalRecord append records
+// (db/log_writer.cc:45-151): every payload byte is read once, stored to its place in the image and folded into its
+// fragment's checksum from the same registers; the header (length, type, log number, and the zero bytes of a
+// block tail in front of it) is written by the lane group of the fragment's first piece, the masked checksum by
+// the group of its last.  The fragmentation itself - where every header goes - is the host's plan
+// (WalFrameEntry): it depends on nothing but the record lengths.
+// A wave takes runs of run_rounds rounds of eight entries.  The pieces of one fragment are consecutive entries of
+// one run; their remainders, multiplied by x^(8 * kWalPiece * pieces behind), are XORed together with a segmented
+// scan over the wave's eight groups and a carry from round to round.
+template <bool NT, bool PHASE_DST>
+__global__ __launch_bounds__(kThreads) void k_wal_frame(WalFrameParams p) {
+  constexpr int G = 8;
+  constexpr int kAuxDwords = AuxDwords<G>::value;
+  __shared__ __align__(16) uint32_t lds[kMainDwords + kAuxDwords];
+  __shared__ uint32_t pow_piece[64];
+  __shared__ uint32_t prefix_reg[16];  // the register after the header bytes the checksum covers, by record type
+
+  const int tid = threadIdx.x;
+  fill_main_tables(lds, p.tab_main, tid);
+  for (int q = tid; q < kAuxDwords / 4; q += kThreads)
+    reinterpret_cast<uint4*>(lds + kMainDwords)[q] = reinterpret_cast<const uint4*>(p.tab_aux)[q];
+  if (tid < 64) pow_piece[tid] = p.pow_piece[tid];
+  __syncthreads();
+  const uint32_t* aux = lds + kMainDwords;
+  if (tid < 16) {
+    // crc = Extend(type_crc_[t], log number) (db/log_writer.cc:115,130-131): the type byte, then for the 11-byte
+    // header the log number's four bytes
+    const uint32_t* T0 = aux + 768;
+    uint32_t reg = 0xffffffffu;
+    reg = T0[(reg ^ (uint32_t)tid) & 0xffu] ^ (reg >> 8);
+    if (p.header_size == kLogRecyclableHeader) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) reg = T0[(reg ^ (p.log_number >> (8 * k))) & 0xffu] ^ (reg >> 8);
+    }
+    prefix_reg[tid] = reg;
+  }
+  __syncthreads();
+
+  const int lane = tid & 63;
+  const int j = lane & (G - 1);
+  const int grp = lane / G;
+  const uint32_t LB = (uint32_t)(lane & 31) * 4u | 0x10000u;
+  const uint32_t hs = p.header_size;
+  const uint32_t R = p.run_rounds;
+  const uint64_t nwaves = (uint64_t)gridDim.x * kWavesPerWg;
+  for (uint64_t run = (uint64_t)blockIdx.x + (uint64_t)gridDim.x * (tid >> 6); run < p.nruns; run += nwaves) {
+    const uint4* e = reinterpret_cast<const uint4*>(p.entries) + run * R * 8u + grp;
+    uint4 cur = e[0];
+    uint32_t carry = 0;  // what the rounds so far hold of a fragment that is not complete yet
+    for (uint32_t r = 0; r < R; ++r) {
+      uint4 nxt = make_uint4(0u, 0u, 0u, 0u);
+      if (r + 1u < R) nxt = e[(r + 1u) * 8u];
+      const uint64_t wa = (uint64_t)cur.x | ((uint64_t)cur.y << 32), wb = (uint64_t)cur.z | ((uint64_t)cur.w << 32);
+      const uint32_t plen = (uint32_t)(wa >> 40) & 0xfffu, q = (uint32_t)(wa >> 52) & 15u;
+      const bool first = (wa >> 56) & 1u, last = (wa >> 57) & 1u, valid = (wa >> 58) & 1u;
+      const uint32_t pad = (uint32_t)(wa >> 59) & 15u;
+      const uint32_t flen = (uint32_t)(wb >> 40) & 0xffffu, type = (uint32_t)(wb >> 56) & 15u;
+      const uint8_t* ptr = p.src + (wa & kFrameOffMask);
+      uint8_t* out = p.dst + (wb & kFrameOffMask);
+      // span_remainder takes a finalised value to continue from: the first piece continues the header bytes,
+      // the others start from a zero register
+      const uint32_t init = first ? ~prefix_reg[type] : 0xffffffffu;
+      const uint32_t core = span_remainder<G, NT, true, PHASE_DST>(lds, LB, lane, ptr, plen, init, valid,
+                                                                    (const uint8_t*)p.tab_main, out, p.sink);
+      // header bytes 4 .. hs-1 (length, type, log number) and the zero bytes in front of the header: one byte per lane
+      if (valid && first) {
+        uint8_t* h = out - hs;
+        const uint32_t bi = 4u + (uint32_t)j;
+        if (bi < hs) {
+          const uint32_t val = bi == 4u ? flen : bi == 5u ? flen >> 8 : bi == 6u ? type : p.log_number >> (8u * (bi - 7u));
+          h[bi] = (uint8_t)val;
+        }
+        if ((uint32_t)j < pad) h[-1 - j] = 0;
+        if ((uint32_t)j + 8u < pad) h[-9 - j] = 0;
+      }
+      // the piece's remainder times x^(8 * kWalPiece * q), on four lanes of the group (see k_wal_fused)
+      uint32_t shifted = core;
+      if (__any(valid && q != 0u)) {
+        const uint32_t rr = __shfl(core, lane | (G - 1));
+        const int l = j & 3;
+        uint32_t b = pow_piece[q * 4u + (uint32_t)l];
+        uint32_t part = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          part ^= ((rr >> (31 - 8 * l - k)) & 1u) ? b : 0u;
+          b = (b >> 1) ^ ((b & 1u) ? 0x82f63b78u : 0u);
+        }
+        part ^= __shfl_xor(part, 1);
+        part ^= __shfl_xor(part, 2);
+        if (q != 0u) shifted = part;
+      }
+      // XOR over the pieces of each fragment: a segmented scan over the eight groups (a fragment's pieces are
+      // neighbours), plus what earlier rounds of this run hold of the fragment the round begins in
+      uint32_t v = valid ? __shfl(shifted, lane | (G - 1)) : 0u;
+      int head = (first || !valid) ? 1 : 0;
+#pragma unroll
+      for (int d = 1; d < 8; d <<= 1) {
+        const uint32_t vu = __shfl_up(v, 8 * d);
+        const int hu = __shfl_up(head, 8 * d);
+        if (grp >= d && !head) {
+          v ^= vu;
+          head = hu;
+        }
+      }
+      if (!head) v ^= carry;
+      carry = (uint32_t)__builtin_amdgcn_readlane((int)((valid && !last) ? v : 0u), 63);
+      if (valid && last && j == G - 1) {
+        const uint32_t crc = ~v;
+        const uint32_t masked = ((crc >> 15) | (crc << 17)) + kMaskDelta;
+        uint8_t* h = out - (flen - plen) - hs;  // the fragment's header: its payload begins flen - plen bytes before this piece
+        __builtin_memcpy(h, &masked, 4);
+      }
+      cur = nxt;
+    }
+  }
+}
+
 // Streaming-read probe: what a kernel that only loads (16 B per lane, whole lines, XOR-folded)
 // reaches on this device; the ceiling the CRC kernels are compared with.
 template <bool NT>
@@ -1305,17 +1531,7 @@ int run_wal_scan(tcrc_ctx* ctx, WalScanParams p, void* stream) {
   const int gi = geo_index(8);
   p.tab_main = ctx->d_tab_main[gi];
   p.tab_aux = ctx->d_tab_aux[gi];
-  // the multipliers of the pieces: worked out once per process (64 modular powers take tens of microseconds on
-  // the host, as long as the scan of a small log takes on the device)
-  struct PiecePowers {
-    uint32_t v[64];
-    PiecePowers() {
-      for (uint32_t q = 0; q < 16; ++q)
-        for (uint32_t l = 0; l < 4; ++l) v[q * 4 + l] = tcrc::gf2_xpow(8ull * kWalPiece * q + 8ull * l);
-    }
-  };
-  static const PiecePowers piece_powers;
-  memcpy(p.pow_piece, piece_powers.v, sizeof(p.pow_piece));
+  memcpy(p.pow_piece, wal_piece_powers(), sizeof(p.pow_piece));
   p.trace = (unsigned long long*)ctx->wal_trace;
   // chunks of up to 64 blocks (one per walker lane), at least two chunks per workgroup
   p.chunk_shift = 6;
@@ -1327,6 +1543,48 @@ int run_wal_scan(tcrc_ctx* ctx, WalScanParams p, void* stream) {
     hipLaunchKernelGGL(k_wal_fused<true>, dim3(wgs), dim3(kThreads), 0, s, p);
   else
     hipLaunchKernelGGL(k_wal_fused<false>, dim3(wgs), dim3(kThreads), 0, s, p);
+  HIP_TRY(hipGetLastError());
+  return TCRC_OK;
+}
+
+
+const uint32_t* wal_piece_powers() {
+  // worked out once per process (64 modular powers take tens of microseconds on the host, as long as the scan of
+  // a small log takes on the device)
+  struct PiecePowers {
+    uint32_t v[64];
+    PiecePowers() {
+      for (uint32_t q = 0; q < 16; ++q)
+        for (uint32_t l = 0; l < 4; ++l) v[q * 4 + l] = tcrc::gf2_xpow(8ull * kWalPiece * q + 8ull * l);
+    }
+  };
+  static const PiecePowers piece_powers;
+  return piece_powers.v;
+}
+
+int run_wal_frame(tcrc_ctx* ctx, WalFrameParams p, bool phase_dst, void* stream) {
+  if (!ctx) return fail(TCRC_ERR_INVALID, "null context");
+  if (p.nruns == 0) return TCRC_OK;
+  if (!p.src || !p.dst || !p.entries || p.run_rounds == 0) return fail(TCRC_ERR_INVALID, "null argument");
+  if (!ctx->d_sink) return fail(TCRC_ERR_INVALID, "context without a store sink");
+  const int gi = geo_index(8);
+  p.tab_main = ctx->d_tab_main[gi];
+  p.tab_aux = ctx->d_tab_aux[gi];
+  p.sink = ctx->d_sink;
+  memcpy(p.pow_piece, wal_piece_powers(), sizeof(p.pow_piece));
+  const uint64_t waves = p.nruns;
+  uint64_t wgs = (waves + kWavesPerWg - 1) / kWavesPerWg;
+  // a small plan spreads over the compute units first (a unit alone pulls its bytes slowly)
+  if (waves < (uint64_t)ctx->cus * kWavesPerWg) wgs = waves < (uint64_t)ctx->cus ? waves : (uint64_t)ctx->cus;
+  if (wgs > (uint64_t)ctx->cus) wgs = (uint64_t)ctx->cus;
+  hipStream_t s = (hipStream_t)stream;
+  if (ctx->nontemporal) {
+    if (phase_dst) hipLaunchKernelGGL((k_wal_frame<true, true>), dim3((unsigned)wgs), dim3(kThreads), 0, s, p);
+    else hipLaunchKernelGGL((k_wal_frame<true, false>), dim3((unsigned)wgs), dim3(kThreads), 0, s, p);
+  } else {
+    if (phase_dst) hipLaunchKernelGGL((k_wal_frame<false, true>), dim3((unsigned)wgs), dim3(kThreads), 0, s, p);
+    else hipLaunchKernelGGL((k_wal_frame<false, false>), dim3((unsigned)wgs), dim3(kThreads), 0, s, p);
+  }
   HIP_TRY(hipGetLastError());
   return TCRC_OK;
 }
@@ -1418,6 +1676,14 @@ int tcrc_init(int device, tcrc_ctx** out) {
       return fail(TCRC_ERR_HIP, std::string("table upload: ") + hipGetErrorString(e));
     }
   }
+  {
+    hipError_t e = hipMalloc((void**)&ctx->d_sink, 4096);
+    if (e != hipSuccess) {
+      tcrc_shutdown(ctx);
+      return fail(TCRC_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+    }
+  }
+  if (const char* e = getenv("TCRC_FRAME_PHASE")) ctx->frame_phase_dst = atoi(e) != 0;
   if (int rc = long_device_setup(ctx)) {
     tcrc_shutdown(ctx);
     return rc;
@@ -1463,6 +1729,12 @@ int tcrc_shutdown(tcrc_ctx* ctx) {
     delete l;
   }
   ctx->lanes.clear();
+  if (ctx->d_sink) (void)hipFree(ctx->d_sink);
+  for (auto& fb : ctx->frame_free) {
+    if (fb.h) (void)hipHostFree(fb.h);
+    if (fb.d) (void)hipFree(fb.d);
+  }
+  if (ctx->frame_stream) (void)hipStreamDestroy(ctx->frame_stream);
   for (auto& e : ctx->pin_free) (void)hipHostFree(e.first);
   if (ctx->stage_ring) (void)hipHostFree(ctx->stage_ring);
   if (ctx->long_pin) (void)hipHostFree(ctx->long_pin);

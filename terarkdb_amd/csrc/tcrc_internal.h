@@ -176,6 +176,35 @@ struct WalScanParams {
   const uint32_t* tab_aux;
 };
 
+// One launch of log framing (tcrc_engine.hip: k_wal_frame).  The host's plan is a list of 16-byte entries, one per
+// piece of at most kWalPiece payload bytes; a physical record (fragment) is one entry, or - above kWalPiece - up
+// to sixteen consecutive ones, cut from its end like the scan's pieces.  The list is dealt to the waves in runs of
+// run_rounds * 8 entries; no fragment's pieces lie in two runs (the plan pads runs with empty entries), so a
+// wave combines them in registers.
+//   word 0 (64 bits): source offset of the piece (40 bits) | piece length << 40 (12 bits) | pieces behind it in
+//                     its fragment << 52 (4 bits) | first piece << 56 | last piece << 57 | valid << 58 |
+//                     zero bytes in front of the fragment's header << 59 (4 bits: a block tail too short for a header)
+//   word 1 (64 bits): image offset of the piece's first payload byte (40 bits) | fragment's payload length << 40
+//                     (16 bits) | record type << 56 (4 bits)
+constexpr uint64_t kFrameOffMask = (1ull << 40) - 1;
+constexpr uint64_t kFrameMaxOffset = 1ull << 40;
+struct WalFrameEntry {
+  uint64_t a, b;
+};
+struct WalFrameParams {
+  const uint8_t* src;
+  uint8_t* dst;
+  const WalFrameEntry* entries;  // nruns * run_rounds * 8
+  uint64_t nruns;
+  uint32_t run_rounds;
+  uint32_t header_size;  // 7 or 11
+  uint32_t log_number;   // low 32 bits, for the 11-byte header
+  uint32_t pow_piece[64];  // as in WalScanParams
+  uint8_t* sink;           // 4 KiB of writable scratch
+  const uint32_t* tab_main;
+  const uint32_t* tab_aux;
+};
+
 // a * b mod P (register convention bit 31 = x^0), 32 shift-and-xor steps.
 __device__ __forceinline__ uint32_t gf2_mulmod_dev(uint32_t a, uint32_t b) {
   uint32_t prod = 0;
@@ -204,6 +233,11 @@ int batch_verify(tcrc_ctx* ctx, const void* d_base, const tcrc_desc* d_desc, uin
 int run_segments(tcrc_ctx* ctx, BatchParams p, const LongArgs& la, void* stream);
 // Launches the fused log scan (tables and powers are filled in here).
 int run_wal_scan(tcrc_ctx* ctx, WalScanParams p, void* stream);
+// Launches log framing over the plan's entries (tables, powers and sink are filled in here).  phase_dst: rows
+// aligned to the image's lines instead of the source's.
+int run_wal_frame(tcrc_ctx* ctx, WalFrameParams p, bool phase_dst, void* stream);
+// The multipliers of the log pieces: [q * 4 + l] = x^(8 * kWalPiece * q + 8 l) mod P, worked out once per process.
+const uint32_t* wal_piece_powers();
 // Per-device set-up of the long-buffer path at tcrc_init (the context's GPU is current): the power tables.
 int long_device_setup(tcrc_ctx* ctx);
 // Gives the context's slice of the static accumulator lines back (tcrc_shutdown).
@@ -296,6 +330,18 @@ struct tcrc_ctx {
   // log-scan scratch (tcrc_wal.hip): one scan at a time per context
   std::mutex wal_mu;
   tcrc_scratch wal_misc, wal_list_counts, wal_list_first, wal_list_temp, wal_frags;
+  uint8_t* d_sink = nullptr;  // 4 KiB of device memory that lane groups without work store to (log framing)
+  // log framing (tcrc_wal.hip): plans upload their piece lists on a stream of the context's own; the buffers
+  // (pinned + device) of freed plans are kept for the next plan (guarded by frame_mu)
+  std::mutex frame_mu;
+  hipStream_t frame_stream = nullptr;
+  struct FrameBuf {
+    void* h = nullptr;
+    void* d = nullptr;
+    size_t bytes = 0;
+  };
+  std::vector<FrameBuf> frame_free;
+  int frame_phase_dst = 1;  // TCRC_FRAME_PHASE: 0 = rows aligned to the source's lines, 1 = to the image's
   void* wal_trace = nullptr;  // development aid: device buffer of 32 x 8 bytes per CU the next scans write timestamps to
   uint64_t wal_calls = 0;  // picks the record-counter slot of a scan (guarded by wal_mu)
   unsigned long long* wal_pin = nullptr;  // 32 words of pinned host memory the scan kernels report record counts into

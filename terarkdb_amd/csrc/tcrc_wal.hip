@@ -67,91 +67,58 @@ __global__ __launch_bounds__(256) void k_wal_list(ListParams p) {
 
 // ---- framing ---------------------------------------------------------------------------------
 
-// One piece of the image: a physical record (header + payload copied from src) or, with type 0xff,
-// a run of zero bytes (the tail of a block too short for a header).
-struct Frag {
-  uint64_t src;  // payload offset in the source
-  uint64_t dst;  // offset of the header (or of the zero run) in the image
-  uint32_t len;  // payload bytes (or zero bytes)
-  uint32_t type;
+constexpr uint32_t kRunRounds = 4;                 // rounds of eight entries a wave takes at a time
+constexpr uint32_t kRunEntries = kRunRounds * 8u;  // (a fragment is at most sixteen pieces, so it always fits a run)
+
+// The fragmentation rules of db/log_writer.cc:45-100 over a list of record lengths.  With `out` it writes the
+// kernel's piece list (WalFrameEntry); without, it only counts.  Returns the image size.
+struct FrameTotals {
+  uint64_t image_bytes = 0, physical = 0, entries = 0;
+  uint32_t block_offset = 0;
 };
-
-struct FrameParams {
-  const uint8_t* src;
-  uint8_t* dst;
-  const Frag* frags;
-  uint32_t nfrags;
-  uint32_t header_size;
-  uint32_t log_number;
-  tcrc_desc* spans;  // out: the checksummed span of every physical record (len 0 for zero runs)
-};
-
-// One wave per piece: header bytes, then the payload in 16-byte steps.
-__global__ __launch_bounds__(256) void k_wal_frame(FrameParams p) {
-  const uint32_t f = blockIdx.x * 4u + (threadIdx.x >> 6);
-  if (f >= p.nfrags) return;
-  const uint32_t lane = threadIdx.x & 63u;
-  const Frag g = p.frags[f];
-  uint8_t* out = p.dst + g.dst;
-  if (g.type == 0xffu) {
-    for (uint32_t i = lane; i < g.len; i += 64u) out[i] = 0;
-    if (lane == 0) p.spans[f] = tcrc_desc{0, 0, 0};
-    return;
-  }
-  const uint32_t hs = p.header_size;
-  if (lane == 0) {
-    out[0] = out[1] = out[2] = out[3] = 0;  // checksum: filled in by the CRC kernel
-    out[4] = (uint8_t)(g.len & 0xffu);
-    out[5] = (uint8_t)(g.len >> 8);
-    out[6] = (uint8_t)g.type;
-    if (hs == kRecyclableHeader) {
-      out[7] = (uint8_t)p.log_number;
-      out[8] = (uint8_t)(p.log_number >> 8);
-      out[9] = (uint8_t)(p.log_number >> 16);
-      out[10] = (uint8_t)(p.log_number >> 24);
-    }
-    tcrc_desc d;
-    d.offset = g.dst + 6;
-    d.len = g.len + hs - 6;
-    d.init = 0;
-    p.spans[f] = d;
-  }
-  const uint8_t* in = p.src + g.src;
-  uint8_t* body = out + hs;
-  const uint32_t whole = g.len & ~15u;
-  for (uint32_t i = lane * 16u; i < whole; i += 1024u) {
-    uint4 v;
-    __builtin_memcpy(&v, in + i, 16);
-    __builtin_memcpy(body + i, &v, 16);
-  }
-  if (lane < (g.len & 15u)) body[whole + lane] = in[whole + lane];
-}
-
-// The fragmentation rules of db/log_writer.cc:45-100 as a list of pieces; returns the image size.
-uint64_t plan_frames(const tcrc_desc* recs, uint64_t n, bool recycle, uint32_t block_offset, std::vector<Frag>* out,
-                     uint32_t* block_offset_out, uint64_t* physical) {
+template <bool EMIT>
+FrameTotals plan_frames(const tcrc_desc* recs, uint64_t n, bool recycle, uint32_t block_offset, WalFrameEntry* out) {
   const uint32_t hs = recycle ? kRecyclableHeader : kHeader;
   const uint32_t base_type = recycle ? 4u : 0u;  // recyclable types are the legacy ones + 4 (db/log_format.h:19-35)
-  uint64_t pos = 0, phys = 0;
+  uint64_t pos = 0, phys = 0, ne = 0;
   uint32_t bo = block_offset;
   for (uint64_t i = 0; i < n; ++i) {
     uint64_t src = recs[i].offset;
     uint32_t left = recs[i].len;
     bool first = true;
     for (;;) {
+      uint32_t pad = 0;
       const uint32_t room = kLogBlock - bo;
-      if (room < hs) {
-        if (room > 0) {
-          if (out) out->push_back(Frag{0, pos, room, 0xffu});
-          pos += room;
-        }
+      if (room < hs) {  // a block tail too short for a header is filled with zeros (db/log_writer.cc:61-73)
+        pad = room;
+        pos += room;
         bo = 0;
       }
       const uint32_t avail = kLogBlock - bo - hs;
       const uint32_t take = left < avail ? left : avail;
       const bool last = take == left;
-      const uint32_t t = first ? (last ? 1u : 2u) : (last ? 4u : 3u);  // full, first, last, middle
-      if (out) out->push_back(Frag{src, pos, take, t + base_type});
+      const uint32_t t = (first ? (last ? 1u : 2u) : (last ? 4u : 3u)) + base_type;  // full, first, last, middle
+      // the fragment's pieces: cut from its end, all but the first kWalPiece bytes long
+      const uint32_t c = take == 0 ? 1u : (take + kWalPiece - 1u) / kWalPiece;
+      if (ne % kRunEntries + c > kRunEntries) {  // would straddle two runs: the rest of this run stays empty
+        const uint64_t fill = kRunEntries - ne % kRunEntries;
+        if (EMIT)
+          for (uint64_t k = 0; k < fill; ++k) out[ne + k] = WalFrameEntry{0, 0};
+        ne += fill;
+      }
+      if (EMIT) {
+        uint64_t s_off = src, d_off = pos + hs;
+        for (uint32_t k = 0; k < c; ++k) {
+          const uint32_t q = c - 1u - k;
+          const uint32_t plen = k == 0 ? take - q * kWalPiece : kWalPiece;
+          out[ne + k].a = s_off | ((uint64_t)plen << 40) | ((uint64_t)q << 52) | ((uint64_t)(k == 0) << 56) |
+                          ((uint64_t)(q == 0) << 57) | (1ull << 58) | ((uint64_t)(k == 0 ? pad : 0u) << 59);
+          out[ne + k].b = d_off | ((uint64_t)take << 40) | ((uint64_t)t << 56);
+          s_off += plen;
+          d_off += plen;
+        }
+      }
+      ne += c;
       pos += hs + take;
       bo += hs + take;
       src += take;
@@ -161,18 +128,185 @@ uint64_t plan_frames(const tcrc_desc* recs, uint64_t n, bool recycle, uint32_t b
       if (left == 0) break;
     }
   }
+  if (EMIT)
+    for (uint64_t k = ne; k % kRunEntries != 0; ++k) out[k] = WalFrameEntry{0, 0};
+  FrameTotals t;
+  t.image_bytes = pos;
+  t.physical = phys;
+  t.entries = (ne + kRunEntries - 1) / kRunEntries * kRunEntries;
   // an image that ends exactly at a block boundary continues at offset 0 of the next block (the writer's own
   // counter stands at 32768 then, db/log_writer.cc:58-80 turns it into 0 at the next record)
-  if (block_offset_out) *block_offset_out = bo == kLogBlock ? 0u : bo;
-  if (physical) *physical = phys;
-  return pos;
+  t.block_offset = bo == kLogBlock ? 0u : bo;
+  return t;
 }
 
 }  // namespace
 
+// A framing plan: where every header and every payload byte of a batch of records goes (host arithmetic on the
+// record lengths), with its piece list on its way to, or already in, device memory.
+struct tcrc_wal_plan {
+  tcrc_ctx* ctx = nullptr;
+  tcrc_ctx::FrameBuf buf;        // pinned and device copy of the piece list
+  const WalFrameEntry* d_entries = nullptr;  // what the kernel reads (the pinned copy itself for a short list)
+  hipEvent_t uploaded = nullptr;  // the copy to the device has finished (NULL: nothing was copied)
+  hipEvent_t used = nullptr;      // the last launch that reads the list has finished
+  bool used_recorded = false;
+  FrameTotals totals;
+  uint64_t src_end = 0;           // one past the last source byte any record names
+  uint32_t header_size = 0, log_number = 0;
+};
+
+namespace {
+constexpr size_t kFrameZeroCopyEntries = 4096;  // up to 64 KiB of entries are read where they lie, in pinned memory
+}
+
 extern "C" uint64_t tcrc_wal_framed_size(const tcrc_desc* h_recs, uint64_t n, int recycle, uint32_t block_offset) {
   if (!h_recs || block_offset >= kLogBlock) return 0;
-  return plan_frames(h_recs, n, recycle != 0, block_offset, nullptr, nullptr, nullptr);
+  return plan_frames<false>(h_recs, n, recycle != 0, block_offset, nullptr).image_bytes;
+}
+
+// Development aid (not part of the C ABI in include/; needs no GPU): the piece list a plan for these records would
+// hold, as pairs of 64-bit words, and the number of entries per run; *count receives the number of entries.
+extern "C" int tcrc_debug_wal_plan_entries(const tcrc_desc* h_recs, uint64_t n, int recycle, uint32_t block_offset,
+                                           uint64_t* out, uint64_t capacity, uint64_t* count, uint32_t* run_entries) {
+  if (!count || (n && !h_recs) || block_offset >= kLogBlock) return fail(TCRC_ERR_INVALID, "bad argument");
+  const FrameTotals t = plan_frames<false>(h_recs, n, recycle != 0, block_offset, nullptr);
+  *count = t.entries;
+  if (run_entries) *run_entries = kRunEntries;
+  if (out) {
+    if (capacity < t.entries) return fail(TCRC_ERR_INVALID, "capacity too small");
+    plan_frames<true>(h_recs, n, recycle != 0, block_offset, (WalFrameEntry*)out);
+  }
+  return TCRC_OK;
+}
+
+extern "C" void tcrc_wal_plan_free(tcrc_wal_plan* plan) {
+  if (!plan) return;
+  tcrc_ctx* ctx = plan->ctx;
+  tcrc_internal::DeviceScope scope(ctx->device);
+  // the buffers go back to the context only when nothing reads them any more
+  if (plan->uploaded) (void)hipEventSynchronize(plan->uploaded);
+  if (plan->used_recorded) (void)hipEventSynchronize(plan->used);
+  if (plan->uploaded) (void)hipEventDestroy(plan->uploaded);
+  if (plan->used) (void)hipEventDestroy(plan->used);
+  if (plan->buf.h) {
+    std::lock_guard<std::mutex> lock(ctx->frame_mu);
+    if (ctx->frame_free.size() < 8) {
+      ctx->frame_free.push_back(plan->buf);
+    } else {
+      (void)hipHostFree(plan->buf.h);
+      if (plan->buf.d) (void)hipFree(plan->buf.d);
+    }
+  }
+  delete plan;
+}
+
+extern "C" int tcrc_wal_plan_create(tcrc_ctx* ctx, const tcrc_desc* h_recs, uint64_t n, uint64_t log_number, int recycle,
+                                    uint32_t block_offset, tcrc_wal_plan** out) {
+  if (!ctx || !out) return fail(TCRC_ERR_INVALID, "null argument");
+  *out = nullptr;
+  if (block_offset >= kLogBlock) return fail(TCRC_ERR_INVALID, "block_offset must be below 32768");
+  if (n && !h_recs) return fail(TCRC_ERR_INVALID, "null argument");
+  // first pass: sizes (and the limits of the entry format)
+  uint64_t src_end = 0;
+  for (uint64_t i = 0; i < n; ++i) {
+    const uint64_t e = h_recs[i].offset + h_recs[i].len;
+    if (e < h_recs[i].offset || e > kFrameMaxOffset) return fail(TCRC_ERR_TOO_LARGE, "record beyond 1 TiB of the source");
+    if (e > src_end) src_end = e;
+  }
+  const FrameTotals t = plan_frames<false>(h_recs, n, recycle != 0, block_offset, nullptr);
+  if (t.image_bytes > kFrameMaxOffset) return fail(TCRC_ERR_TOO_LARGE, "framed image above 1 TiB");
+  tcrc_wal_plan* plan = new tcrc_wal_plan();
+  plan->ctx = ctx;
+  plan->totals = t;
+  plan->src_end = src_end;
+  plan->header_size = recycle ? kRecyclableHeader : kHeader;
+  plan->log_number = (uint32_t)log_number;
+  if (t.entries == 0) {
+    *out = plan;
+    return TCRC_OK;
+  }
+  tcrc_internal::DeviceScope scope(ctx->device);
+  auto bail = [&](int code, const std::string& msg) {
+    tcrc_wal_plan_free(plan);
+    return fail(code, msg);
+  };
+  if (scope.err != hipSuccess) return bail(TCRC_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(scope.err));
+  const size_t bytes = (size_t)t.entries * sizeof(WalFrameEntry);
+  const bool zero_copy = t.entries <= kFrameZeroCopyEntries;
+  {
+    // smallest kept buffer that is large enough (and has a device side if one is needed)
+    std::lock_guard<std::mutex> lock(ctx->frame_mu);
+    size_t best = ctx->frame_free.size();
+    for (size_t i = 0; i < ctx->frame_free.size(); ++i) {
+      const auto& fb = ctx->frame_free[i];
+      if (fb.bytes >= bytes && (zero_copy || fb.d) && (best == ctx->frame_free.size() || fb.bytes < ctx->frame_free[best].bytes))
+        best = i;
+    }
+    if (best != ctx->frame_free.size()) {
+      plan->buf = ctx->frame_free[best];
+      ctx->frame_free.erase(ctx->frame_free.begin() + best);
+    }
+    if (!ctx->frame_stream) {
+      const hipError_t e = hipStreamCreateWithFlags(&ctx->frame_stream, hipStreamNonBlocking);
+      if (e != hipSuccess) return bail(TCRC_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+    }
+  }
+  if (!plan->buf.h) {
+    const size_t want = zero_copy ? kFrameZeroCopyEntries * sizeof(WalFrameEntry) : bytes + bytes / 4;
+    hipError_t e = hipHostMalloc(&plan->buf.h, want, hipHostMallocMapped);
+    if (e == hipSuccess && !zero_copy) e = hipMalloc(&plan->buf.d, want);
+    if (e != hipSuccess) return bail(TCRC_ERR_HIP, std::string("plan buffers: ") + hipGetErrorString(e));
+    plan->buf.bytes = want;
+  }
+  plan_frames<true>(h_recs, n, recycle != 0, block_offset, (WalFrameEntry*)plan->buf.h);
+  hipError_t e = hipEventCreateWithFlags(&plan->used, hipEventDisableTiming);
+  if (e != hipSuccess) return bail(TCRC_ERR_HIP, std::string("hipEventCreate: ") + hipGetErrorString(e));
+  if (zero_copy) {
+    void* dev = nullptr;
+    e = hipHostGetDevicePointer(&dev, plan->buf.h, 0);
+    if (e != hipSuccess) return bail(TCRC_ERR_HIP, std::string("hipHostGetDevicePointer: ") + hipGetErrorString(e));
+    plan->d_entries = (const WalFrameEntry*)dev;
+  } else {
+    e = hipEventCreateWithFlags(&plan->uploaded, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipMemcpyAsync(plan->buf.d, plan->buf.h, bytes, hipMemcpyHostToDevice, ctx->frame_stream);
+    if (e == hipSuccess) e = hipEventRecord(plan->uploaded, ctx->frame_stream);
+    if (e != hipSuccess) return bail(TCRC_ERR_HIP, std::string("plan upload: ") + hipGetErrorString(e));
+    plan->d_entries = (const WalFrameEntry*)plan->buf.d;
+  }
+  *out = plan;
+  return TCRC_OK;
+}
+
+extern "C" uint64_t tcrc_wal_plan_image_bytes(const tcrc_wal_plan* plan) { return plan ? plan->totals.image_bytes : 0; }
+extern "C" uint32_t tcrc_wal_plan_block_offset(const tcrc_wal_plan* plan) { return plan ? plan->totals.block_offset : 0; }
+extern "C" uint64_t tcrc_wal_plan_physical_records(const tcrc_wal_plan* plan) { return plan ? plan->totals.physical : 0; }
+
+extern "C" int tcrc_dev_wal_frame_enqueue(tcrc_ctx* ctx, tcrc_wal_plan* plan, const void* d_src, void* d_dst,
+                                          uint64_t dst_capacity, void* stream) {
+  if (!ctx || !plan) return fail(TCRC_ERR_INVALID, "null argument");
+  if (plan->ctx != ctx) return fail(TCRC_ERR_INVALID, "the plan belongs to another context");
+  if (plan->totals.entries == 0) return TCRC_OK;
+  if (!d_src || !d_dst) return fail(TCRC_ERR_INVALID, "null argument");
+  if (plan->totals.image_bytes > dst_capacity) return fail(TCRC_ERR_INVALID, "dst_capacity is smaller than the framed size");
+  // the image must not overlap the records it is made from (payload bytes are stored while others are still unread)
+  const uintptr_t s0 = (uintptr_t)d_src, s1 = s0 + plan->src_end, t0 = (uintptr_t)d_dst, t1 = t0 + plan->totals.image_bytes;
+  if (s0 < t1 && t0 < s1) return fail(TCRC_ERR_INVALID, "d_dst overlaps d_src");
+  TCRC_DEVICE_SCOPE(ctx);
+  hipStream_t s = (hipStream_t)stream;
+  if (plan->uploaded) HIP_TRY(hipStreamWaitEvent(s, plan->uploaded, 0));
+  WalFrameParams f{};
+  f.src = (const uint8_t*)d_src;
+  f.dst = (uint8_t*)d_dst;
+  f.entries = plan->d_entries;
+  f.nruns = plan->totals.entries / kRunEntries;
+  f.run_rounds = kRunRounds;
+  f.header_size = plan->header_size;
+  f.log_number = plan->log_number;
+  if (int rc = run_wal_frame(ctx, f, ctx->frame_phase_dst != 0, stream)) return rc;
+  HIP_TRY(hipEventRecord(plan->used, s));
+  plan->used_recorded = true;
+  return TCRC_OK;
 }
 
 extern "C" int tcrc_dev_wal_frame(tcrc_ctx* ctx, const void* d_src, const tcrc_desc* h_recs, uint64_t n,
@@ -186,43 +320,21 @@ extern "C" int tcrc_dev_wal_frame(tcrc_ctx* ctx, const void* d_src, const tcrc_d
   if (block_offset >= kLogBlock) return fail(TCRC_ERR_INVALID, "block_offset must be below 32768");
   if (n == 0) return TCRC_OK;
   if (!d_src || !h_recs || !d_dst) return fail(TCRC_ERR_INVALID, "null argument");
-  std::vector<Frag> frags;
-  uint32_t bo = 0;
-  uint64_t phys = 0;
-  const uint64_t total = plan_frames(h_recs, n, recycle != 0, block_offset, &frags, &bo, &phys);
-  if (total > dst_capacity) return fail(TCRC_ERR_INVALID, "dst_capacity is smaller than the framed size");
-  if (frags.size() >= (1ull << 32)) return fail(TCRC_ERR_TOO_LARGE, "too many physical records in one call");
-  TCRC_DEVICE_SCOPE(ctx);
-  std::lock_guard<std::mutex> lock(ctx->wal_mu);
-  hipStream_t s = (hipStream_t)stream;
-  const size_t frag_bytes = frags.size() * sizeof(Frag);
-  const size_t span_off = (frag_bytes + 255) & ~(size_t)255;
-  if (int rc = scratch_reserve(ctx, &ctx->wal_frags, span_off + frags.size() * sizeof(tcrc_desc))) return rc;
-  StreamGuard guard(s);  // `frags` must not go away with its copy in flight
-  HIP_TRY(hipMemcpyAsync(ctx->wal_frags.p, frags.data(), frag_bytes, hipMemcpyHostToDevice, s));
-  FrameParams f{};
-  f.src = (const uint8_t*)d_src;
-  f.dst = (uint8_t*)d_dst;
-  f.frags = (const Frag*)ctx->wal_frags.p;
-  f.nfrags = (uint32_t)frags.size();
-  f.header_size = recycle ? kRecyclableHeader : kHeader;
-  f.log_number = (uint32_t)log_number;
-  f.spans = (tcrc_desc*)((uint8_t*)ctx->wal_frags.p + span_off);
-  hipLaunchKernelGGL(k_wal_frame, dim3((f.nfrags + 3u) / 4u), dim3(256), 0, s, f);
-  HIP_TRY(hipGetLastError());
-  BatchParams p{};
-  p.base = f.dst;
-  p.desc = f.spans;
-  p.n = frags.size();
-  p.uniform_suffix = -1;
-  p.flags = TCRC_F_MASK | kFlagStampBefore;  // zero runs have empty spans, which the kernel does not stamp
-  if (int rc = run_batch(ctx, p, stream)) return rc;
-  guard.dismiss();
-  HIP_TRY(hipStreamSynchronize(s));  // the piece list was copied from pageable memory
-  if (h_written) *h_written = total;
-  if (block_offset_out) *block_offset_out = bo;
-  if (h_physical_records) *h_physical_records = phys;
-  return TCRC_OK;
+  tcrc_wal_plan* plan = nullptr;
+  if (int rc = tcrc_wal_plan_create(ctx, h_recs, n, log_number, recycle, block_offset, &plan)) return rc;
+  int rc = tcrc_dev_wal_frame_enqueue(ctx, plan, d_src, d_dst, dst_capacity, stream);
+  if (rc == TCRC_OK) {
+    TCRC_DEVICE_SCOPE(ctx);
+    const hipError_t e = hipStreamSynchronize((hipStream_t)stream);  // "returns with the image complete"
+    if (e != hipSuccess) rc = fail(TCRC_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
+  }
+  if (rc == TCRC_OK) {
+    if (h_written) *h_written = plan->totals.image_bytes;
+    if (block_offset_out) *block_offset_out = plan->totals.block_offset;
+    if (h_physical_records) *h_physical_records = plan->totals.physical;
+  }
+  tcrc_wal_plan_free(plan);
+  return rc;
 }
 
 extern "C" int tcrc_dev_wal_list(tcrc_ctx* ctx, const void* d_img, uint64_t size, uint64_t log_number,

@@ -304,3 +304,58 @@ def test_scan_of_garbage_and_preallocated_images_matches_oracle():
             assert (got == want).all(), (k, log_number, np.nonzero((got != want).any(axis=1))[0][:5])
             assert n == int(want[:, 0].sum())
     eng.close()
+
+
+@pytest.mark.parametrize("phase", ["0", "1"])
+@pytest.mark.parametrize("recycle", [False, True])
+def test_framing_plan_is_enqueued_twice_over_other_bytes(recycle, phase):
+    """plan / enqueue: the plan knows the image's size, block offset and record count before anything runs; one
+    plan framed twice over different source bytes gives the CPU writer's image both times.  Both row alignments
+    of the kernel (source lines, image lines) are exercised."""
+    import os
+    import gpu_util as G
+    os.environ["TCRC_FRAME_PHASE"] = phase
+    try:
+        eng = G.engine()
+    finally:
+        os.environ.pop("TCRC_FRAME_PHASE", None)
+    rnd = O.Random(17)
+    hs = 11 if recycle else 7
+    # whole-block fragments (sixteen pieces), fragments just above one and two pieces, empty and tiny records,
+    # lengths around the sixteen-byte row edge, and a skewed mix
+    lens = [32768 - hs, 0, 2048, 2049, 4096, 4097, 15, 16, 17, 31, 33, 70000, 1, 0, 0, 2047, 6000, 131071]
+    lens += [rnd.skewed(15) for _ in range(400)]
+    total = sum(lens)
+    offs, pos = [], 5
+    for ln in lens:
+        offs.append(pos)
+        pos += ln + (ln % 3)  # gaps between the records in the source
+    plan = eng.wal_plan(offs, lens, 77, recycle, block_offset=32768 - hs - 3)
+    dst = torch.full((plan.image_bytes + 64,), 0xEE, dtype=torch.uint8, device="cuda")
+    for seed in (5, 6):
+        src = O.splitmix((pos + 64 + 7) // 8 * 8, seed)
+        records = [src[o:o + ln].tobytes() for o, ln in zip(offs, lens)]
+        # the CPU writer continuing a log that stands at the same block offset
+        want, start = _oracle_image(records, recycle, 77, prefix=[b"x" * (32768 - hs - 3 - hs)])
+        assert start == 32768 - hs - 3
+        assert plan.image_bytes == len(want) and plan.block_offset == (start + len(want)) % 32768
+        dsrc = G.to_dev(src)
+        dst.fill_(0xEE)
+        eng.wal_frame_enqueue(plan, dsrc, dst)
+        torch.cuda.synchronize()
+        got = dst.cpu().numpy()
+        assert got[:len(want)].tobytes() == want, seed
+        assert (got[len(want):] == 0xEE).all()
+    assert plan.physical_records >= len(lens) and total > 0
+    import terarkdb_amd.capi as capi
+    big = torch.zeros(dsrc.numel() + plan.image_bytes + 256, dtype=torch.uint8, device="cuda")
+    with pytest.raises(capi.TcrcError, match="overlaps"):
+        eng.wal_frame_enqueue(plan, big[:dsrc.numel()], big[128:])
+    with pytest.raises(capi.TcrcError, match="smaller"):
+        eng.wal_frame_enqueue(plan, dsrc, dst[:100])
+    plan.close()
+    empty = eng.wal_plan([], [], 1, recycle)
+    assert (empty.image_bytes, empty.block_offset, empty.physical_records) == (0, 0, 0)
+    eng.wal_frame_enqueue(empty, dsrc, dst)
+    empty.close()
+    eng.close()
