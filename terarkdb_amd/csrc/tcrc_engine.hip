@@ -1255,9 +1255,9 @@ __global__ __launch_bounds__(kThreads) void k_wal_fused(WalScanParams p) {
 // block tail in front of it) is written by the lane group of the fragment's first piece, the masked checksum by
 // the group of its last.  The fragmentation itself - where every header goes - is the host's plan
 // (WalFrameEntry): it depends on nothing but the record lengths.
-// A wave takes runs of run_rounds rounds of eight entries.  The pieces of one fragment are consecutive entries of
-// one run; their remainders, multiplied by x^(8 * kWalPiece * pieces behind), are XORed together with a segmented
-// scan over the wave's eight groups and a carry from round to round.
+// A wave takes rounds of eight entries.  The pieces of one fragment are neighbouring entries of one round; their
+// remainders, multiplied by x^(8 * kFramePiece * pieces behind), are XORed together with a segmented scan over the
+// wave's eight groups.
 template <bool NT, bool PHASE_DST>
 __global__ __launch_bounds__(kThreads) void k_wal_frame(WalFrameParams p) {
   constexpr int G = 8;
@@ -1292,57 +1292,58 @@ __global__ __launch_bounds__(kThreads) void k_wal_frame(WalFrameParams p) {
   const int grp = lane / G;
   const uint32_t LB = (uint32_t)(lane & 31) * 4u | 0x10000u;
   const uint32_t hs = p.header_size;
-  const uint32_t R = p.run_rounds;
+  // rounds are dealt to workgroups first, then to the waves of a workgroup (a small plan spreads over all CUs)
+  const uint64_t wave = (uint64_t)blockIdx.x + (uint64_t)gridDim.x * (tid >> 6);
   const uint64_t nwaves = (uint64_t)gridDim.x * kWavesPerWg;
-  for (uint64_t run = (uint64_t)blockIdx.x + (uint64_t)gridDim.x * (tid >> 6); run < p.nruns; run += nwaves) {
-    const uint4* e = reinterpret_cast<const uint4*>(p.entries) + run * R * 8u + grp;
-    uint4 cur = e[0];
-    uint32_t carry = 0;  // what the rounds so far hold of a fragment that is not complete yet
-    for (uint32_t r = 0; r < R; ++r) {
-      uint4 nxt = make_uint4(0u, 0u, 0u, 0u);
-      if (r + 1u < R) nxt = e[(r + 1u) * 8u];
-      const uint64_t wa = (uint64_t)cur.x | ((uint64_t)cur.y << 32), wb = (uint64_t)cur.z | ((uint64_t)cur.w << 32);
-      const uint32_t plen = (uint32_t)(wa >> 40) & 0xfffu, q = (uint32_t)(wa >> 52) & 15u;
-      const bool first = (wa >> 56) & 1u, last = (wa >> 57) & 1u, valid = (wa >> 58) & 1u;
-      const uint32_t pad = (uint32_t)(wa >> 59) & 15u;
-      const uint32_t flen = (uint32_t)(wb >> 40) & 0xffffu, type = (uint32_t)(wb >> 56) & 15u;
-      const uint8_t* ptr = p.src + (wa & kFrameOffMask);
-      uint8_t* out = p.dst + (wb & kFrameOffMask);
-      // span_remainder takes a finalised value to continue from: the first piece continues the header bytes,
-      // the others start from a zero register
-      const uint32_t init = first ? ~prefix_reg[type] : 0xffffffffu;
-      const uint32_t core = span_remainder<G, NT, true, PHASE_DST>(lds, LB, lane, ptr, plen, init, valid,
-                                                                    (const uint8_t*)p.tab_main, out, p.sink);
-      // header bytes 4 .. hs-1 (length, type, log number) and the zero bytes in front of the header: one byte per lane
-      if (valid && first) {
-        uint8_t* h = out - hs;
-        const uint32_t bi = 4u + (uint32_t)j;
-        if (bi < hs) {
-          const uint32_t val = bi == 4u ? flen : bi == 5u ? flen >> 8 : bi == 6u ? type : p.log_number >> (8u * (bi - 7u));
-          h[bi] = (uint8_t)val;
-        }
-        if ((uint32_t)j < pad) h[-1 - j] = 0;
-        if ((uint32_t)j + 8u < pad) h[-9 - j] = 0;
+  const uint4* entries = reinterpret_cast<const uint4*>(p.entries);
+  uint4 nxt = make_uint4(0u, 0u, 0u, 0u);
+  if (wave < p.nrounds) nxt = entries[wave * 8u + grp];
+  for (uint64_t round = wave; round < p.nrounds; round += nwaves) {
+    const uint4 cur = nxt;
+    if (round + nwaves < p.nrounds) nxt = entries[(round + nwaves) * 8u + grp];  // on its way while this round runs
+    const uint64_t wa = (uint64_t)cur.x | ((uint64_t)cur.y << 32), wb = (uint64_t)cur.z | ((uint64_t)cur.w << 32);
+    const uint32_t plen = (uint32_t)(wa >> 40) & 0x1fffu, q = (uint32_t)(wa >> 53) & 7u;
+    const bool first = (wa >> 56) & 1u, last = (wa >> 57) & 1u, valid = (wa >> 58) & 1u;
+    const uint32_t pad = (uint32_t)(wa >> 59) & 15u;
+    const uint32_t flen = (uint32_t)(wb >> 40) & 0xffffu, type = (uint32_t)(wb >> 56) & 15u;
+    const uint8_t* ptr = p.src + (wa & kFrameOffMask);
+    uint8_t* out = p.dst + (wb & kFrameOffMask);
+    // span_remainder takes a finalised value to continue from: the first piece continues the header bytes,
+    // the others start from a zero register
+    const uint32_t init = first ? ~prefix_reg[type] : 0xffffffffu;
+    const uint32_t core = span_remainder<G, NT, true, PHASE_DST>(lds, LB, lane, ptr, plen, init, valid,
+                                                                  (const uint8_t*)p.tab_main, out, p.sink);
+    // header bytes 4 .. hs-1 (length, type, log number) and the zero bytes in front of the header: one byte per lane
+    if (valid && first) {
+      uint8_t* h = out - hs;
+      const uint32_t bi = 4u + (uint32_t)j;
+      if (bi < hs) {
+        const uint32_t val = bi == 4u ? flen : bi == 5u ? flen >> 8 : bi == 6u ? type : p.log_number >> (8u * (bi - 7u));
+        h[bi] = (uint8_t)val;
       }
-      // the piece's remainder times x^(8 * kWalPiece * q), on four lanes of the group (see k_wal_fused)
-      uint32_t shifted = core;
-      if (__any(valid && q != 0u)) {
-        const uint32_t rr = __shfl(core, lane | (G - 1));
-        const int l = j & 3;
-        uint32_t b = pow_piece[q * 4u + (uint32_t)l];
-        uint32_t part = 0;
+      if ((uint32_t)j < pad) h[-1 - j] = 0;
+      if ((uint32_t)j + 8u < pad) h[-9 - j] = 0;
+    }
+    // the piece's remainder times x^(8 * kFramePiece * q), on four lanes of the group (see k_wal_fused)
+    uint32_t shifted = core;
+    if (__any(valid && q != 0u)) {
+      const uint32_t rr = __shfl(core, lane | (G - 1));
+      const int l = j & 3;
+      uint32_t b = pow_piece[q * (kFramePiece / kWalPiece) * 4u + (uint32_t)l];
+      uint32_t part = 0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          part ^= ((rr >> (31 - 8 * l - k)) & 1u) ? b : 0u;
-          b = (b >> 1) ^ ((b & 1u) ? 0x82f63b78u : 0u);
-        }
-        part ^= __shfl_xor(part, 1);
-        part ^= __shfl_xor(part, 2);
-        if (q != 0u) shifted = part;
+      for (int k = 0; k < 8; ++k) {
+        part ^= ((rr >> (31 - 8 * l - k)) & 1u) ? b : 0u;
+        b = (b >> 1) ^ ((b & 1u) ? 0x82f63b78u : 0u);
       }
-      // XOR over the pieces of each fragment: a segmented scan over the eight groups (a fragment's pieces are
-      // neighbours), plus what earlier rounds of this run hold of the fragment the round begins in
-      uint32_t v = valid ? __shfl(shifted, lane | (G - 1)) : 0u;
+      part ^= __shfl_xor(part, 1);
+      part ^= __shfl_xor(part, 2);
+      if (q != 0u) shifted = part;
+    }
+    // XOR over the pieces of each fragment: a segmented scan over the eight groups (a fragment's pieces are
+    // neighbours, all in this round)
+    uint32_t v = valid ? __shfl(shifted, lane | (G - 1)) : 0u;
+    if (__any(valid && !first)) {
       int head = (first || !valid) ? 1 : 0;
 #pragma unroll
       for (int d = 1; d < 8; d <<= 1) {
@@ -1353,15 +1354,12 @@ __global__ __launch_bounds__(kThreads) void k_wal_frame(WalFrameParams p) {
           head = hu;
         }
       }
-      if (!head) v ^= carry;
-      carry = (uint32_t)__builtin_amdgcn_readlane((int)((valid && !last) ? v : 0u), 63);
-      if (valid && last && j == G - 1) {
-        const uint32_t crc = ~v;
-        const uint32_t masked = ((crc >> 15) | (crc << 17)) + kMaskDelta;
-        uint8_t* h = out - (flen - plen) - hs;  // the fragment's header: its payload begins flen - plen bytes before this piece
-        __builtin_memcpy(h, &masked, 4);
-      }
-      cur = nxt;
+    }
+    if (valid && last && j == G - 1) {
+      const uint32_t crc = ~v;
+      const uint32_t masked = ((crc >> 15) | (crc << 17)) + kMaskDelta;
+      uint8_t* h = out - (flen - plen) - hs;  // the fragment's header: its payload begins flen - plen bytes before this piece
+      __builtin_memcpy(h, &masked, 4);
     }
   }
 }
@@ -1564,19 +1562,15 @@ const uint32_t* wal_piece_powers() {
 
 int run_wal_frame(tcrc_ctx* ctx, WalFrameParams p, bool phase_dst, void* stream) {
   if (!ctx) return fail(TCRC_ERR_INVALID, "null context");
-  if (p.nruns == 0) return TCRC_OK;
-  if (!p.src || !p.dst || !p.entries || p.run_rounds == 0) return fail(TCRC_ERR_INVALID, "null argument");
+  if (p.nrounds == 0) return TCRC_OK;
+  if (!p.src || !p.dst || !p.entries) return fail(TCRC_ERR_INVALID, "null argument");
   if (!ctx->d_sink) return fail(TCRC_ERR_INVALID, "context without a store sink");
   const int gi = geo_index(8);
   p.tab_main = ctx->d_tab_main[gi];
   p.tab_aux = ctx->d_tab_aux[gi];
   p.sink = ctx->d_sink;
   memcpy(p.pow_piece, wal_piece_powers(), sizeof(p.pow_piece));
-  const uint64_t waves = p.nruns;
-  uint64_t wgs = (waves + kWavesPerWg - 1) / kWavesPerWg;
-  // a small plan spreads over the compute units first (a unit alone pulls its bytes slowly)
-  if (waves < (uint64_t)ctx->cus * kWavesPerWg) wgs = waves < (uint64_t)ctx->cus ? waves : (uint64_t)ctx->cus;
-  if (wgs > (uint64_t)ctx->cus) wgs = (uint64_t)ctx->cus;
+  const uint64_t wgs = p.nrounds < (uint64_t)ctx->cus ? p.nrounds : (uint64_t)ctx->cus;
   hipStream_t s = (hipStream_t)stream;
   if (ctx->nontemporal) {
     if (phase_dst) hipLaunchKernelGGL((k_wal_frame<true, true>), dim3((unsigned)wgs), dim3(kThreads), 0, s, p);

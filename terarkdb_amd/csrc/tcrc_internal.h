@@ -177,15 +177,15 @@ struct WalScanParams {
 };
 
 // One launch of log framing (tcrc_engine.hip: k_wal_frame).  The host's plan is a list of 16-byte entries, one per
-// piece of at most kWalPiece payload bytes; a physical record (fragment) is one entry, or - above kWalPiece - up
-// to sixteen consecutive ones, cut from its end like the scan's pieces.  The list is dealt to the waves in runs of
-// run_rounds * 8 entries; no fragment's pieces lie in two runs (the plan pads runs with empty entries), so a
-// wave combines them in registers.
-//   word 0 (64 bits): source offset of the piece (40 bits) | piece length << 40 (12 bits) | pieces behind it in
-//                     its fragment << 52 (4 bits) | first piece << 56 | last piece << 57 | valid << 58 |
+// piece of at most kFramePiece payload bytes; a physical record (fragment) is one entry, or - above kFramePiece -
+// up to eight neighbouring ones in ONE round of eight entries, cut from its end like the scan's pieces, so that
+// the wave that takes the round combines them in registers.  Rounds are independent of each other.
+//   word 0 (64 bits): source offset of the piece (40 bits) | piece length << 40 (13 bits) | pieces behind it in
+//                     its fragment << 53 (3 bits) | first piece << 56 | last piece << 57 | valid << 58 |
 //                     zero bytes in front of the fragment's header << 59 (4 bits: a block tail too short for a header)
 //   word 1 (64 bits): image offset of the piece's first payload byte (40 bits) | fragment's payload length << 40
 //                     (16 bits) | record type << 56 (4 bits)
+constexpr uint32_t kFramePiece = 4096;
 constexpr uint64_t kFrameOffMask = (1ull << 40) - 1;
 constexpr uint64_t kFrameMaxOffset = 1ull << 40;
 struct WalFrameEntry {
@@ -194,9 +194,8 @@ struct WalFrameEntry {
 struct WalFrameParams {
   const uint8_t* src;
   uint8_t* dst;
-  const WalFrameEntry* entries;  // nruns * run_rounds * 8
-  uint64_t nruns;
-  uint32_t run_rounds;
+  const WalFrameEntry* entries;  // nrounds * 8
+  uint64_t nrounds;
   uint32_t header_size;  // 7 or 11
   uint32_t log_number;   // low 32 bits, for the 11-byte header
   uint32_t pow_piece[64];  // as in WalScanParams
@@ -341,7 +340,7 @@ struct tcrc_ctx {
     size_t bytes = 0;
   };
   std::vector<FrameBuf> frame_free;
-  int frame_phase_dst = 1;  // TCRC_FRAME_PHASE: 0 = rows aligned to the source's lines, 1 = to the image's
+  int frame_phase_dst = 0;  // TCRC_FRAME_PHASE: 0 = rows aligned to the source's lines (measured faster), 1 = to the image's
   void* wal_trace = nullptr;  // development aid: device buffer of 32 x 8 bytes per CU the next scans write timestamps to
   uint64_t wal_calls = 0;  // picks the record-counter slot of a scan (guarded by wal_mu)
   unsigned long long* wal_pin = nullptr;  // 32 words of pinned host memory the scan kernels report record counts into

@@ -67,20 +67,18 @@ __global__ __launch_bounds__(256) void k_wal_list(ListParams p) {
 
 // ---- framing ---------------------------------------------------------------------------------
 
-constexpr uint32_t kRunRounds = 4;                 // rounds of eight entries a wave takes at a time
-constexpr uint32_t kRunEntries = kRunRounds * 8u;  // (a fragment is at most sixteen pieces, so it always fits a run)
-
-// The fragmentation rules of db/log_writer.cc:45-100 over a list of record lengths.  With `out` it writes the
-// kernel's piece list (WalFrameEntry); without, it only counts.  Returns the image size.
+// The fragmentation rules of db/log_writer.cc:45-100 over a list of record lengths: calls
+// f(source offset, image offset of the header, payload bytes, type, zero bytes in front of the header) for every
+// physical record in file order and returns the totals.
 struct FrameTotals {
   uint64_t image_bytes = 0, physical = 0, entries = 0;
   uint32_t block_offset = 0;
 };
-template <bool EMIT>
-FrameTotals plan_frames(const tcrc_desc* recs, uint64_t n, bool recycle, uint32_t block_offset, WalFrameEntry* out) {
+template <typename F>
+FrameTotals for_each_fragment(const tcrc_desc* recs, uint64_t n, bool recycle, uint32_t block_offset, F&& f) {
   const uint32_t hs = recycle ? kRecyclableHeader : kHeader;
   const uint32_t base_type = recycle ? 4u : 0u;  // recyclable types are the legacy ones + 4 (db/log_format.h:19-35)
-  uint64_t pos = 0, phys = 0, ne = 0;
+  uint64_t pos = 0, phys = 0;
   uint32_t bo = block_offset;
   for (uint64_t i = 0; i < n; ++i) {
     uint64_t src = recs[i].offset;
@@ -98,27 +96,7 @@ FrameTotals plan_frames(const tcrc_desc* recs, uint64_t n, bool recycle, uint32_
       const uint32_t take = left < avail ? left : avail;
       const bool last = take == left;
       const uint32_t t = (first ? (last ? 1u : 2u) : (last ? 4u : 3u)) + base_type;  // full, first, last, middle
-      // the fragment's pieces: cut from its end, all but the first kWalPiece bytes long
-      const uint32_t c = take == 0 ? 1u : (take + kWalPiece - 1u) / kWalPiece;
-      if (ne % kRunEntries + c > kRunEntries) {  // would straddle two runs: the rest of this run stays empty
-        const uint64_t fill = kRunEntries - ne % kRunEntries;
-        if (EMIT)
-          for (uint64_t k = 0; k < fill; ++k) out[ne + k] = WalFrameEntry{0, 0};
-        ne += fill;
-      }
-      if (EMIT) {
-        uint64_t s_off = src, d_off = pos + hs;
-        for (uint32_t k = 0; k < c; ++k) {
-          const uint32_t q = c - 1u - k;
-          const uint32_t plen = k == 0 ? take - q * kWalPiece : kWalPiece;
-          out[ne + k].a = s_off | ((uint64_t)plen << 40) | ((uint64_t)q << 52) | ((uint64_t)(k == 0) << 56) |
-                          ((uint64_t)(q == 0) << 57) | (1ull << 58) | ((uint64_t)(k == 0 ? pad : 0u) << 59);
-          out[ne + k].b = d_off | ((uint64_t)take << 40) | ((uint64_t)t << 56);
-          s_off += plen;
-          d_off += plen;
-        }
-      }
-      ne += c;
+      f(src, pos, take, t, pad);
       pos += hs + take;
       bo += hs + take;
       src += take;
@@ -128,16 +106,101 @@ FrameTotals plan_frames(const tcrc_desc* recs, uint64_t n, bool recycle, uint32_
       if (left == 0) break;
     }
   }
-  if (EMIT)
-    for (uint64_t k = ne; k % kRunEntries != 0; ++k) out[k] = WalFrameEntry{0, 0};
   FrameTotals t;
   t.image_bytes = pos;
   t.physical = phys;
-  t.entries = (ne + kRunEntries - 1) / kRunEntries * kRunEntries;
   // an image that ends exactly at a block boundary continues at offset 0 of the next block (the writer's own
   // counter stands at 32768 then, db/log_writer.cc:58-80 turns it into 0 at the next record)
   t.block_offset = bo == kLogBlock ? 0u : bo;
   return t;
+}
+
+// The kernel's piece list for these records.  A fragment is cut, from its end, into pieces of kFramePiece bytes
+// (the first one may be shorter): at most eight, which all go into ONE round of eight entries, so that the wave
+// that takes the round has the whole fragment.  Entries need not follow the file's order - each says where its
+// bytes come from and go to - so the list is laid out for the kernel: first the rounds that hold fragments of
+// several pieces (packed in file order; a fragment that does not fit the open round closes it), then the
+// one-piece fragments, longest first in classes of 256 bytes, filling the holes of those rounds and then rounds
+// of their own - a round takes as long as its longest entry, and entries of a class are alike.
+constexpr uint32_t kFrameClasses = kFramePiece / 256u + 1u;
+struct FrameLayout {
+  uint64_t multi_rounds = 0, singles = 0, holes = 0;
+  uint64_t class_first[kFrameClasses + 1] = {};  // position of a class's first fragment in the order of one-piece fragments
+  std::vector<uint32_t> hole_slots;              // entry indices of the holes in the rounds of several pieces, in order
+};
+inline uint32_t frame_pieces(uint32_t take) { return take == 0 ? 1u : (take + kFramePiece - 1u) / kFramePiece; }
+inline uint32_t frame_class(uint32_t take) { return kFrameClasses - 1u - (take + 255u) / 256u; }  // longest first
+
+FrameTotals frame_layout(const tcrc_desc* recs, uint64_t n, bool recycle, uint32_t block_offset, FrameLayout* lay) {
+  uint64_t per_class[kFrameClasses] = {};
+  uint32_t free_slots = 0;  // of the open round of several pieces
+  FrameTotals t = for_each_fragment(recs, n, recycle, block_offset,
+                                    [&](uint64_t, uint64_t, uint32_t take, uint32_t, uint32_t) {
+    const uint32_t c = frame_pieces(take);
+    if (c == 1u) {
+      ++per_class[frame_class(take)];
+      return;
+    }
+    if (c > free_slots) {  // the open round's holes are left for one-piece fragments
+      for (uint32_t k = 0; k < free_slots; ++k) lay->hole_slots.push_back((uint32_t)(lay->multi_rounds * 8u - free_slots + k));
+      ++lay->multi_rounds;
+      free_slots = 8u;
+    }
+    free_slots -= c;
+  });
+  for (uint32_t k = 0; k < free_slots; ++k) lay->hole_slots.push_back((uint32_t)(lay->multi_rounds * 8u - free_slots + k));
+  lay->holes = lay->hole_slots.size();
+  uint64_t at = 0;
+  for (uint32_t cl = 0; cl < kFrameClasses; ++cl) {
+    lay->class_first[cl] = at;
+    at += per_class[cl];
+  }
+  lay->class_first[kFrameClasses] = at;
+  lay->singles = at;
+  const uint64_t beyond = at > lay->holes ? at - lay->holes : 0;
+  t.entries = lay->multi_rounds * 8u + (beyond + 7u) / 8u * 8u;
+  return t;
+}
+
+void frame_emit(const tcrc_desc* recs, uint64_t n, bool recycle, uint32_t block_offset, const FrameLayout& lay,
+                uint64_t entries, WalFrameEntry* out) {
+  const uint32_t hs = recycle ? kRecyclableHeader : kHeader;
+  // what no fragment will fill: holes beyond the one-piece fragments, and the end of the last round
+  for (uint64_t k = lay.singles; k < lay.holes; ++k) out[lay.hole_slots[k]] = WalFrameEntry{0, 0};
+  const uint64_t beyond = lay.singles > lay.holes ? lay.singles - lay.holes : 0;
+  for (uint64_t k = lay.multi_rounds * 8u + beyond; k < entries; ++k) out[k] = WalFrameEntry{0, 0};
+  uint64_t class_next[kFrameClasses];
+  for (uint32_t cl = 0; cl < kFrameClasses; ++cl) class_next[cl] = lay.class_first[cl];
+  uint64_t multi_round = 0;
+  uint32_t free_slots = 0;
+  bool any_multi = false;
+  for_each_fragment(recs, n, recycle, block_offset,
+                    [&](uint64_t src, uint64_t pos, uint32_t take, uint32_t type, uint32_t pad) {
+    const uint32_t c = frame_pieces(take);
+    uint64_t slot;
+    if (c == 1u) {
+      const uint64_t k = class_next[frame_class(take)]++;
+      slot = k < lay.holes ? lay.hole_slots[k] : lay.multi_rounds * 8u + (k - lay.holes);
+    } else {
+      if (c > free_slots) {
+        if (any_multi) ++multi_round;
+        any_multi = true;
+        free_slots = 8u;
+      }
+      slot = multi_round * 8u + (8u - free_slots);
+      free_slots -= c;
+    }
+    uint64_t s_off = src, d_off = pos + hs;
+    for (uint32_t k = 0; k < c; ++k) {
+      const uint32_t q = c - 1u - k;
+      const uint32_t plen = k == 0 ? take - q * kFramePiece : kFramePiece;
+      out[slot + k].a = s_off | ((uint64_t)plen << 40) | ((uint64_t)q << 53) | ((uint64_t)(k == 0) << 56) |
+                        ((uint64_t)(q == 0) << 57) | (1ull << 58) | ((uint64_t)(k == 0 ? pad : 0u) << 59);
+      out[slot + k].b = d_off | ((uint64_t)take << 40) | ((uint64_t)type << 56);
+      s_off += plen;
+      d_off += plen;
+    }
+  });
 }
 
 }  // namespace
@@ -162,7 +225,8 @@ constexpr size_t kFrameZeroCopyEntries = 4096;  // up to 64 KiB of entries are r
 
 extern "C" uint64_t tcrc_wal_framed_size(const tcrc_desc* h_recs, uint64_t n, int recycle, uint32_t block_offset) {
   if (!h_recs || block_offset >= kLogBlock) return 0;
-  return plan_frames<false>(h_recs, n, recycle != 0, block_offset, nullptr).image_bytes;
+  return for_each_fragment(h_recs, n, recycle != 0, block_offset, [](uint64_t, uint64_t, uint32_t, uint32_t, uint32_t) {})
+      .image_bytes;
 }
 
 // Development aid (not part of the C ABI in include/; needs no GPU): the piece list a plan for these records would
@@ -170,12 +234,13 @@ extern "C" uint64_t tcrc_wal_framed_size(const tcrc_desc* h_recs, uint64_t n, in
 extern "C" int tcrc_debug_wal_plan_entries(const tcrc_desc* h_recs, uint64_t n, int recycle, uint32_t block_offset,
                                            uint64_t* out, uint64_t capacity, uint64_t* count, uint32_t* run_entries) {
   if (!count || (n && !h_recs) || block_offset >= kLogBlock) return fail(TCRC_ERR_INVALID, "bad argument");
-  const FrameTotals t = plan_frames<false>(h_recs, n, recycle != 0, block_offset, nullptr);
+  FrameLayout lay;
+  const FrameTotals t = frame_layout(h_recs, n, recycle != 0, block_offset, &lay);
   *count = t.entries;
-  if (run_entries) *run_entries = kRunEntries;
+  if (run_entries) *run_entries = 8;
   if (out) {
     if (capacity < t.entries) return fail(TCRC_ERR_INVALID, "capacity too small");
-    plan_frames<true>(h_recs, n, recycle != 0, block_offset, (WalFrameEntry*)out);
+    frame_emit(h_recs, n, recycle != 0, block_offset, lay, t.entries, (WalFrameEntry*)out);
   }
   return TCRC_OK;
 }
@@ -214,7 +279,9 @@ extern "C" int tcrc_wal_plan_create(tcrc_ctx* ctx, const tcrc_desc* h_recs, uint
     if (e < h_recs[i].offset || e > kFrameMaxOffset) return fail(TCRC_ERR_TOO_LARGE, "record beyond 1 TiB of the source");
     if (e > src_end) src_end = e;
   }
-  const FrameTotals t = plan_frames<false>(h_recs, n, recycle != 0, block_offset, nullptr);
+  FrameLayout lay;
+  const FrameTotals t = frame_layout(h_recs, n, recycle != 0, block_offset, &lay);
+  if (t.entries >= (1ull << 32)) return fail(TCRC_ERR_TOO_LARGE, "too many physical records in one plan");
   if (t.image_bytes > kFrameMaxOffset) return fail(TCRC_ERR_TOO_LARGE, "framed image above 1 TiB");
   tcrc_wal_plan* plan = new tcrc_wal_plan();
   plan->ctx = ctx;
@@ -259,7 +326,7 @@ extern "C" int tcrc_wal_plan_create(tcrc_ctx* ctx, const tcrc_desc* h_recs, uint
     if (e != hipSuccess) return bail(TCRC_ERR_HIP, std::string("plan buffers: ") + hipGetErrorString(e));
     plan->buf.bytes = want;
   }
-  plan_frames<true>(h_recs, n, recycle != 0, block_offset, (WalFrameEntry*)plan->buf.h);
+  frame_emit(h_recs, n, recycle != 0, block_offset, lay, t.entries, (WalFrameEntry*)plan->buf.h);
   hipError_t e = hipEventCreateWithFlags(&plan->used, hipEventDisableTiming);
   if (e != hipSuccess) return bail(TCRC_ERR_HIP, std::string("hipEventCreate: ") + hipGetErrorString(e));
   if (zero_copy) {
@@ -299,8 +366,7 @@ extern "C" int tcrc_dev_wal_frame_enqueue(tcrc_ctx* ctx, tcrc_wal_plan* plan, co
   f.src = (const uint8_t*)d_src;
   f.dst = (uint8_t*)d_dst;
   f.entries = plan->d_entries;
-  f.nruns = plan->totals.entries / kRunEntries;
-  f.run_rounds = kRunRounds;
+  f.nrounds = plan->totals.entries / 8u;
   f.header_size = plan->header_size;
   f.log_number = plan->log_number;
   if (int rc = run_wal_frame(ctx, f, ctx->frame_phase_dst != 0, stream)) return rc;

@@ -8,7 +8,7 @@ import pytest
 
 import oracle_lib as O
 
-PIECE = 2048
+PIECE = 4096
 
 
 def plan_entries(lens, offs, recycle, block_offset):
@@ -30,7 +30,7 @@ def plan_entries(lens, offs, recycle, block_offset):
 
 def decode(e):
     a, b = int(e[0]), int(e[1])
-    return dict(src=a & ((1 << 40) - 1), plen=(a >> 40) & 0xfff, q=(a >> 52) & 15, first=(a >> 56) & 1,
+    return dict(src=a & ((1 << 40) - 1), plen=(a >> 40) & 0x1fff, q=(a >> 53) & 7, first=(a >> 56) & 1,
                 last=(a >> 57) & 1, valid=(a >> 58) & 1, pad=(a >> 59) & 15, dst=b & ((1 << 40) - 1),
                 flen=(b >> 40) & 0xffff, type=(b >> 56) & 15)
 
@@ -64,10 +64,12 @@ def test_piece_list_matches_the_cpu_writers_records(recycle, start):
     phys = [r for r in phys if r[0] >= base]
 
     ent, run = plan_entries(lens, offs, recycle, start % 32768)
-    assert run == 32 and len(ent) % run == 0
+    assert run == 8 and len(ent) % run == 0
     frags, cur = [], None
     for i, raw in enumerate(ent):
         d = decode(raw)
+        if i % run == 0:
+            assert cur is None, "a fragment's pieces lie in two rounds"
         if not d["valid"]:
             assert cur is None, "an empty entry inside a fragment"
             assert int(raw[0]) == 0 and int(raw[1]) == 0
@@ -79,17 +81,25 @@ def test_piece_list_matches_the_cpu_writers_records(recycle, start):
             assert cur is not None
             cur["pieces"].append(d)
         if d["last"]:
-            assert cur["first_index"] // run == i // run, "a fragment's pieces lie in two runs"
+            assert cur["first_index"] // run == i // run, "a fragment's pieces lie in two rounds"
             frags.append(cur)
             cur = None
     assert cur is None
     assert len(frags) == len(phys)
+    # the list is laid out for the kernel, not in file order: rounds of several-piece fragments first, then the
+    # one-piece fragments longest first in classes of 256 bytes
+    multi_rounds = {f["first_index"] // run for f in frags if len(f["pieces"]) > 1}
+    assert multi_rounds == set(range(len(multi_rounds)))
+    singles_after = [f["pieces"][0]["plen"] for f in frags if f["first_index"] // run >= len(multi_rounds)]
+    classes = [(ln + 255) // 256 for ln in singles_after]
+    assert classes == sorted(classes, reverse=True)
+    frags.sort(key=lambda f: f["pieces"][0]["dst"])
     ri, consumed = -1, 0
     for f, r in zip(frags, phys):
         off, rtype, ln = int(r[0]), int(r[1]), int(r[2])
         ps = f["pieces"]
         c = len(ps)
-        assert c == max(1, -(-ln // PIECE)) and c <= 16
+        assert c == max(1, -(-ln // PIECE)) and c <= 8
         assert [p["q"] for p in ps] == list(range(c - 1, -1, -1))
         assert all(p["flen"] == ln and p["type"] == rtype for p in ps)
         assert all(p["plen"] == PIECE for p in ps[1:]) and sum(p["plen"] for p in ps) == ln

@@ -96,6 +96,18 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / args.launches
+        # for scale: the runtime's own device-to-device copy of the payload (no headers, no checksums)
+        flat = torch.empty(payload, dtype=torch.uint8, device="cuda")
+        for _ in range(5):
+            flat.copy_(dsrc[:payload])
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record()
+        for _ in range(args.launches):
+            flat.copy_(dsrc[:payload])
+        c1.record()
+        torch.cuda.synchronize()
+        copy_ms = c0.elapsed_time(c1) / args.launches
+        del flat
         # the one-call form, host clock, to completion
         written, bo, phys = C.c_uint64(0), C.c_uint32(0), C.c_uint64(0)
         best_call = None
@@ -113,6 +125,8 @@ def main():
             "kernel_us_per_launch": round(ms * 1e3, 2), "payload_GBps": round(payload / (ms * 1e-3) / 1e9, 1),
             "traffic_GBps_read_plus_write": round((payload + plan.image_bytes) / (ms * 1e-3) / 1e9, 1),
             "frac_hbm_peak_read_plus_write": round((payload + plan.image_bytes) / (ms * 1e-3) / 8e12, 4),
+            "plain_device_copy_us": round(copy_ms * 1e3, 2),
+            "plain_device_copy_GBps_read_plus_write": round(2 * payload / (copy_ms * 1e-3) / 1e9, 1),
             "plan_create_us": round(best_plan * 1e6, 1), "one_call_us": round(best_call * 1e6, 1),
             "python_plan_us": round(t_plan_py * 1e6, 1),
             "bytes_identical_to_cpu_writer": same, "launches": args.launches,
