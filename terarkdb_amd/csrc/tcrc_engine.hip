@@ -1100,9 +1100,15 @@ __global__ __launch_bounds__(kThreads) void k_wal_fused(WalScanParams p) {
   };
 
   uint32_t spins = 0;
+  unsigned long long tr_time = 0, tr_from = 0;  // trace: time in the walker's own code, and its visits
+  uint32_t tr_visits = 0;
   for (;;) {
     if (lds_load(&ctl[2])) break;  // some wave of the workgroup gave up waiting
     uint32_t t = 0;
+    if (p.trace && wave == 0 && !w_done) {
+      tr_from = wall_clock64();
+      ++tr_visits;
+    }
     if (wave == 0 && !w_done) {
       __builtin_amdgcn_s_setprio(3);  // the walk is the critical path of a workgroup with little to do
       // The walker.  While its records find room it only walks; when they do not, it takes a round itself if one
@@ -1114,6 +1120,7 @@ __global__ __launch_bounds__(kThreads) void k_wal_fused(WalScanParams p) {
       do {
         blocked = walk_step(hdr);
       } while (!blocked && !w_done && !lds_load(&ctl[2]));
+      if (p.trace) tr_time += wall_clock64() - tr_from;
       if (!blocked) {
         if (w_done) {
           stamp(2);
@@ -1221,6 +1228,10 @@ __global__ __launch_bounds__(kThreads) void k_wal_fused(WalScanParams p) {
     }
   }
   stamp(31);
+  if (p.trace && tid == 0) {
+    p.trace[blockIdx.x * 32u + 4u] = tr_time + 1ull;
+    p.trace[blockIdx.x * 32u + 6u] = tr_visits + 1ull;
+  }
   if (wave == 0) {
     uint32_t total = w_records;
 #pragma unroll
@@ -1247,6 +1258,567 @@ __global__ __launch_bounds__(kThreads) void k_wal_fused(WalScanParams p) {
   }
 }
 
+
+// ---- log scan, walker and placer apart ------------------------------------------------------------------
+// The same scan with the header walk cut down to what is sequential.  In k_wal_fused one dependent step per record
+// decodes the header, works out the record's pieces, finds room in the ring and slots for them and writes them;
+// here wave 0 only chases headers (fetch, the structural checks of db/log_reader.cc:317-384, advance) and appends
+// one 8-byte (block, start, length) entry per checksummed span to a list in LDS, in one ballot.  Wave 1 takes up to
+// 64 entries of that list per step - parallel over records, no header chain in its way - and does what is left:
+// piece counts, places in the ring from ballots, slots for spans of several pieces, the ring writes.  Both go on
+// to checksum rounds like the other fourteen waves when they have nothing else to do.
+constexpr uint32_t kSplitRingRounds = 144;   // rounds of 8 entries in the ring (9 KiB)
+constexpr uint32_t kSplitListEntries = 256;  // spans the walker may be ahead of the placer (2 KiB)
+constexpr uint32_t kSplitHelpMin = 12;       // walker and placer take a round themselves only with this many waiting
+// Small records: how far in front of the walker's cursor the placer asks for the image's 64-byte sectors, up to
+// which span length a record counts as small, and the number of waiting rounds from which on it stops asking
+constexpr uint32_t kSplitAhead = 1024, kSplitAheadSpan = 640, kSplitAheadBacklog = 32;
+// classes of pieces that share rounds: longer than kSplitLong bytes, longer than kSplitShort, and the rest
+constexpr uint32_t kSplitLong = 1024, kSplitShort = 256;
+
+template <bool NT>
+__global__ __launch_bounds__(kThreads) void k_wal_split(WalScanParams p) {
+  constexpr int G = 8;
+  constexpr int kAuxDwords = AuxDwords<G>::value;
+  constexpr uint32_t RR = kSplitRingRounds;
+  __shared__ __align__(16) uint32_t lds[kMainDwords + kAuxDwords];
+  __shared__ uint2 ring[RR * 8];
+  __shared__ uint32_t seq[RR];
+  __shared__ uint2 rlist[kSplitListEntries];
+  __shared__ WalSlot slots[kWalSlots];
+  // [0] next ticket, [1] rounds in all once everything is placed (till then ~0), [2] set when a wait ran out,
+  // [3] rounds that are out, [4] spans the walker has listed (bit 31: and the walk is over), [5] spans the placer has taken
+  __shared__ uint32_t ctl[8];
+  __shared__ uint32_t pow_piece[64];  // [q * 4 + l]: x^(8 * kWalPiece * q) * x^(8 l)
+  __shared__ uint32_t ahead_sink[64];  // where the sectors asked for ahead of the walker land (never read)
+
+  const int tid = threadIdx.x;
+  // trace (development aid): [0] start, [1] tables in place, [2] walk over, [3] everything placed, [31] end of wave 0
+  auto stamp = [&](uint32_t at, int who) {
+    if (p.trace && tid == who && at < 32u) p.trace[blockIdx.x * 32u + at] = wall_clock64();
+  };
+  stamp(0, 0);
+  fill_main_tables(lds, p.tab_main, tid);
+  for (int q = tid; q < kAuxDwords / 4; q += kThreads)
+    reinterpret_cast<uint4*>(lds + kMainDwords)[q] = reinterpret_cast<const uint4*>(p.tab_aux)[q];
+  for (uint32_t i = tid; i < RR; i += kThreads) seq[i] = i;
+  for (int i = tid; i < kWalSlots; i += kThreads) slots[i].remaining = 0u;
+  if (tid < 64) pow_piece[tid] = p.pow_piece[tid];
+  if (tid < 8) ctl[tid] = tid == 1 ? 0xffffffffu : 0u;
+  __syncthreads();
+  stamp(1, 0);
+
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int j = lane & (G - 1);
+  const int grp = lane / G;
+  const uint32_t LB = (uint32_t)(lane & 31) * 4u | 0x10000u;
+
+  // this workgroup's blocks: as in k_wal_fused
+  const uint32_t cs = p.chunk_shift;
+  const uint32_t nchunks = (p.nblocks + (1u << cs) - 1u) >> cs;
+  const uint32_t my_chunks = nchunks > blockIdx.x ? (nchunks - blockIdx.x + gridDim.x - 1u) / gridDim.x : 0u;
+  const uint32_t b_hi = my_chunks << cs;
+  auto block_of = [&](uint32_t v) -> uint32_t {
+    return (((v >> cs) * gridDim.x + blockIdx.x) << cs) + (v & ((1u << cs) - 1u));
+  };
+  auto block_end = [&](uint32_t blk) -> uint64_t {
+    const uint64_t e = (uint64_t)blk * kLogBlockBytes + kLogBlockBytes;
+    return e < p.size ? e : p.size;
+  };
+  auto uni = [](uint32_t v) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+  auto lds_acquire = [](const uint32_t* q) -> uint32_t {
+    return __hip_atomic_load(q, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+  auto lds_release = [](uint32_t* q, uint32_t v) {
+    __hip_atomic_store(q, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+
+  // ---- the walker (wave 0): every lane chases the headers of one block at a time
+  uint32_t w_next = 0;  // next number to hand to an idle lane (the same in every lane)
+  uint32_t w_blk = 0, w_pos = 0, w_k = 0, w_records = 0;
+  uint32_t w_len = 0;          // bytes of the lane's block that are in the image (32768 but for the image's last block)
+  auto w_ptr = [&]() -> const uint8_t* { return p.img + (uint64_t)w_blk * kLogBlockBytes; };  // the block's first byte
+  bool w_active = false, w_done = false;
+  // bit 0: w_hdr holds header bytes 4..11 under the cursor, fetched with one 8-byte load (>= 12 bytes were left);
+  // bit 1: the lane's record found no room in the list, so w_hdr is not the header under its cursor
+  // (one word on purpose: two flags set in the two arms of a branch end up in memory, behind a selected address)
+  uint32_t w_flags = 0;
+  WalHeader w_hdr = {0u, 0u};
+  uint32_t l_wr = 0;                     // spans listed so far (the same in every lane)
+  uint32_t l_room = kSplitListEntries;   // places in the list known to be free
+  const uint32_t ln32 = (uint32_t)p.log_number;
+  const bool ln_fits = (p.log_number >> 32) == 0;  // a recyclable header holds 32 bits: a larger log number never matches
+  // One step: every active lane looks at the header under its cursor (fetched by the step before) and lists the
+  // record's checksummed span.  Returns true if the list had no room for some record.
+  // The common case - at least twelve bytes left in the block, a header that passes every check of
+  // db/log_reader.cc:317-384 - is decoded without a branch, in 32-bit arithmetic relative to the block; whatever
+  // else a lane meets (the last bytes of a block, a header that ends the block's walk) takes the general
+  // wal_fetch / wal_decode, which the whole wave then steps through once.
+  auto walk_step = [&]() -> bool {
+    WalHeader hdr = w_hdr;
+    const unsigned long long idle = __ballot(!w_active);
+    if (idle && w_next < b_hi) {
+      const uint32_t nv = w_next + lanes_below(idle);
+      const uint32_t nb = block_of(nv);
+      if (!w_active && nv < b_hi && nb < p.nblocks) {
+        w_active = true;
+        w_blk = nb;
+        w_pos = 0;
+        w_k = 0;
+        const uint64_t bbase = (uint64_t)nb * kLogBlockBytes;
+        w_len = (uint32_t)(block_end(nb) - bbase);
+        p.blocks[nb].first_bad = 0xffffffffu;  // lowered by whoever finds a bad checksum in the block
+        w_flags = w_len >= 12u ? 1u : 0u;
+        if (w_flags) {
+          uint2 w;
+          __builtin_memcpy(&w, w_ptr() + 4, 8);
+          hdr.lo = w.x;
+          hdr.hi = w.y;
+        }
+      }
+      const uint32_t handed = w_next + (uint32_t)__popcll(idle);
+      w_next = handed < b_hi ? handed : b_hi;
+    }
+    if (!__any(w_active)) {
+      if (lane == 0) lds_store(&ctl[4], l_wr | 0x80000000u);  // the count is final
+      w_done = true;
+      return false;
+    }
+    const uint32_t rem = w_len - w_pos;
+    const uint32_t type = (hdr.lo >> 16) & 0xffu;
+    uint32_t len = hdr.lo & 0xffffu;
+    const bool recyc = type - 5u < 4u;
+    uint32_t hs = recyc ? kLogRecyclableHeader : kLogHeader;
+    const uint32_t lognum = __builtin_amdgcn_alignbyte(hdr.hi, hdr.lo, 3);  // header bytes 7..10
+    bool ok = w_active && (w_flags & 1u) != 0u && hs + len <= rem && (hdr.lo & 0xffffffu) != 0u &&
+              (!recyc || (lognum == ln32 && ln_fits));
+    if (__any(w_active && !ok)) {
+      if (w_active && !ok) {
+        const uint64_t base = (uint64_t)w_blk * kLogBlockBytes;
+        const uint64_t end = base + w_len;
+        const bool last = p.tail && end == p.size;
+        uint32_t code = 0;
+        WalHeader h = hdr;
+        if (!(w_flags & 1u)) h = wal_fetch(p.img, base + w_pos, end);
+        ok = wal_decode(h, base + w_pos, end, last, p.log_number, &hs, &len, &code);
+        if (!ok) {  // the block's walk ends here
+          tcrc_wal_block* b = p.blocks + w_blk;
+          b->n_records = w_k;
+          b->end_offset = w_pos;
+          b->end_code = code;
+          w_records += w_k;
+          w_active = false;
+        }
+      }
+    }
+    // the next header is asked for before anything else is done with this record
+    const uint32_t npos = w_pos + hs + len;
+    const bool fastn = ok && w_len - npos >= 12u;
+    WalHeader nxt = {0u, 0u};
+    if (fastn) {
+      uint2 w;
+      __builtin_memcpy(&w, w_ptr() + npos + 4u, 8);
+      nxt.lo = w.x;
+      nxt.hi = w.y;
+    }
+    const unsigned long long m_ok = __ballot(ok);
+    const uint32_t cnt = (uint32_t)__popcll(m_ok);
+    if (cnt > l_room) l_room = kSplitListEntries - (l_wr - uni(lds_acquire(&ctl[5])));
+    const uint32_t below = lanes_below(m_ok);
+    if (ok && below < l_room) {
+      // the CRC covers the type byte, the log number if any, and the payload: [pos + 6, pos + hs + len)
+      rlist[(l_wr + below) % kSplitListEntries] = make_uint2(w_blk, (w_pos + 6u) | ((len + hs - 6u) << 15));
+      w_pos = npos;
+      ++w_k;
+      w_flags = fastn ? 1u : 0u;
+    } else if (ok) {
+      w_flags |= 2u;
+    }
+    // Unconditionally, so that the load is waited for where the next step decodes it and not here: a lane whose
+    // record found no room ends the walk loop (the step returns true) and fetches its header again when the
+    // walker comes back.
+    w_hdr = nxt;
+    const uint32_t nfit = cnt < l_room ? cnt : l_room;
+    if (nfit) {
+      l_wr += nfit;
+      l_room -= nfit;
+      // (no release fence: the LDS performs one wave's operations in the order they were issued, so whoever
+      // sees the count sees the entries; the fence would make every step wait for its own write to come back)
+      asm volatile("" ::: "memory");
+      if (lane == 0) lds_store(&ctl[4], l_wr);
+    }
+    return cnt > nfit;
+  };
+
+  // ---- the placer (wave 1): up to 64 listed spans per step
+  uint32_t p_rd = 0;     // spans taken from the list so far (the same in every lane)
+  uint32_t p_count = 0;  // entries written to the ring so far
+  uint32_t p_open = 0;   // rounds [0, p_open) are known to be the placer's to write or already written
+  uint32_t p_spans = 0;  // spans of several pieces so far: span n uses slot n mod kWalSlots
+  bool p_done = false;
+  // Returns 0 when every span it took found room, 1 when the ring or the slots had no room for some, 2 when the
+  // list was empty.
+  auto place_step = [&]() -> int {
+    // One look at the ring before anything else: with less than a round's worth of room the step could place
+    // next to nothing, and all it would do is work out that it is blocked (a scan that waits for its checksum
+    // waves comes here after every round the placer takes itself).
+    if (p_open * 8u - p_count < 8u) {
+      const uint32_t t = p_open + (uint32_t)lane;
+      const bool mine = (uint32_t)lane < kWalStepRounds && lds_load(&seq[t % RR]) == t;
+      const unsigned long long m = __ballot(mine);
+      p_open += m == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~m);
+      if (p_open > (p_count >> 3) + kWalStepRounds) p_open = (p_count >> 3) + kWalStepRounds;
+      if (p_open * 8u - p_count < 8u && (p_count & 7u) == 0u) return 1;
+    }
+    const uint32_t listed = uni(lds_acquire(&ctl[4]));
+    const uint32_t over = listed >> 31;
+    const uint32_t avail = (listed & 0x7fffffffu) - p_rd;
+    if (avail == 0u) {
+      if (!over) return 2;
+      // Everything is placed: the last round is padded with empty entries and goes out, and the number of rounds
+      // is made known.  (The round is the placer's: p_open covers a round it has written entries into.)
+      const uint32_t pad = (8u - (p_count & 7u)) & 7u;
+      if (pad) {
+        if ((uint32_t)lane < pad) ring[(p_count + lane) % (RR * 8u)] = make_uint2(0u, 0u);
+        if (lane == 0) lds_release(&seq[(p_count >> 3) % RR], (p_count >> 3) + 1u);
+      }
+      if (lane == 0) {
+        lds_store(&ctl[3], (p_count + 7u) >> 3);
+        lds_store(&ctl[1], (p_count + 7u) >> 3);
+      }
+      p_done = true;
+      return 0;
+    }
+    const uint32_t n = avail < 64u ? avail : 64u;
+    const bool has = (uint32_t)lane < n;
+    uint2 e = make_uint2(0u, 0u);
+    if (has) e = rlist[(p_rd + lane) % kSplitListEntries];
+    const uint32_t blk = e.x, start = e.y & 0x7fffu, span = e.y >> 15;
+    const uint32_t c = has ? (span + kWalPiece - 1u) / kWalPiece : 0u;  // 1..16 pieces
+    const bool multi = c > 1u;
+    // Small records.  The walk of a block is a chain of dependent loads, and with records of a hundred bytes
+    // every one of them is the first touch of its line: a trip to memory per record.  Loads return to a wave in
+    // the order it issued them, so the walker cannot ask ahead for itself without waiting for what it asked; the
+    // placer can - it sees where every cursor is a moment after the walker has moved it, and asks for the
+    // 64-byte sectors that the record just listed brought within kSplitAhead bytes of the cursor (straight into
+    // a few words of LDS that nobody reads: the point is the copy the L2 keeps).  Not while rounds pile up:
+    // then the checksum waves are what the scan waits for, and they would find the lines evicted again.
+    if (!(p.tune & 1u) && __any(has && span <= kSplitAheadSpan)) {
+      const uint32_t out = p_count >> 3, taken = uni(lds_load(&ctl[0]));
+      if (taken + kSplitAheadBacklog > out) {
+        const uint64_t bbase = (uint64_t)blk * kLogBlockBytes;
+        const uint32_t blen = (uint32_t)(block_end(blk) - bbase);
+        const uint32_t lim = blen >= 4u ? ((blen - 4u) >> 6) + 1u : 0u;  // sectors of the block that hold four readable bytes
+        // sectors reached so far: up to (header position + kSplitAhead) / 64; a block's first record starts from nothing
+        const uint32_t from = start == 6u ? 0u : ((start - 6u + kSplitAhead) >> 6) + 1u;
+        uint32_t to = ((start + span + kSplitAhead) >> 6) + 1u;
+        if (to > lim) to = lim;
+        if (to > from + 40u) to = from + 40u;
+        if (!has || span > kSplitAheadSpan) to = 0u;
+        typedef const uint32_t __attribute__((address_space(1)))* gp32;
+        typedef uint32_t __attribute__((address_space(3)))* lp32;
+        const uint8_t* bp = p.img + bbase;
+        for (uint32_t sct = from; sct < to; ++sct)
+          __builtin_amdgcn_global_load_lds((gp32)(bp + (size_t)sct * 64u), (lp32)ahead_sink, 4, 0, 0);
+      }
+    }
+    // counts and places from ballots, one per bit of the piece count (one in all when no span is longer than a piece)
+    const unsigned long long m_multi = __ballot(multi);
+    uint32_t step_entries = 0, below_e = 0;
+    if (m_multi == 0ull) {
+      step_entries = n;
+      below_e = (uint32_t)lane;
+    } else {
+#pragma unroll
+      for (int b = 0; b < 5; ++b) {
+        const unsigned long long mb = __ballot((c >> b) & 1u);
+        step_entries += (uint32_t)__popcll(mb) << b;
+        below_e += lanes_below(mb) << b;
+      }
+    }
+    if (step_entries > p_open * 8u - p_count) {
+      const uint32_t t = p_open + (uint32_t)lane;
+      const bool mine = (uint32_t)lane < kWalStepRounds && lds_load(&seq[t % RR]) == t;
+      const unsigned long long m = __ballot(mine);
+      p_open += m == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~m);
+      if (p_open > (p_count >> 3) + kWalStepRounds) p_open = (p_count >> 3) + kWalStepRounds;
+    }
+    const uint32_t room = p_open * 8u - p_count;
+    // spans take room in list order; those that no longer fit stay in the list.  A span of several pieces also
+    // needs its slot to be free.
+    const uint32_t upto_e = below_e + c;
+    const uint32_t my_span = p_spans + lanes_below(m_multi);
+    bool before_busy = true;
+    if (m_multi != 0ull) {
+      const bool slot_busy = multi && lds_load(&slots[my_span % kWalSlots].remaining) != 0u;
+      const unsigned long long m_busy = __ballot(slot_busy || (multi && my_span - p_spans >= (uint32_t)kWalSlots));
+      before_busy = m_busy == 0ull || lane < __builtin_ctzll(m_busy);
+    }
+    const bool fits = has && upto_e <= room && before_busy;
+    const unsigned long long m_fit = __ballot(fits);  // a run of lanes from lane 0 on
+    // Where the step's entries go.  A round takes as long as its longest entry, so entries that are alike should
+    // share rounds: the step's entries are laid down by class - first all pieces longer than kSplitLong bytes
+    // (every piece but a span's first is kWalPiece long), then the first pieces above kSplitShort bytes, then the
+    // short ones - each class in lane order.  The places come from ballots over the lanes that fit.
+    const uint32_t p0 = span - (c - 1u) * kWalPiece;  // the span's first piece: 1..kWalPiece bytes
+    const bool cls_a = fits && p0 > kSplitLong, cls_b = fits && !cls_a && p0 > kSplitShort, cls_c = fits && !cls_a && !cls_b;
+    uint32_t at0 = 0, at_rest = 0;  // where the span's first piece goes, and its other pieces (all of the first class)
+    if (p.sort_classes && m_fit) {
+      const uint32_t n_a = fits ? c - 1u + (cls_a ? 1u : 0u) : 0u;
+      uint32_t tot_a = 0, below_a = 0;
+      if ((m_fit & m_multi) == 0ull) {
+        const unsigned long long ma = __ballot(cls_a);
+        tot_a = (uint32_t)__popcll(ma);
+        below_a = lanes_below(ma);
+      } else {
+#pragma unroll
+        for (int b = 0; b < 5; ++b) {
+          const unsigned long long mb = __ballot((n_a >> b) & 1u);
+          tot_a += (uint32_t)__popcll(mb) << b;
+          below_a += lanes_below(mb) << b;
+        }
+      }
+      const unsigned long long mb = __ballot(cls_b), mc = __ballot(cls_c);
+      const uint32_t tot_b = (uint32_t)__popcll(mb);
+      at_rest = p_count + below_a + (cls_a ? 1u : 0u);
+      at0 = cls_a ? p_count + below_a : cls_b ? p_count + tot_a + lanes_below(mb) : p_count + tot_a + tot_b + lanes_below(mc);
+    } else {
+      at0 = p_count + upto_e - c;
+      at_rest = at0 + 1u;
+    }
+    if (fits) {
+      const uint32_t slot = multi ? my_span % kWalSlots : kWalNoSlot;
+      const uint32_t stop = start + span;
+      for (uint32_t i = 0; i < c; ++i) {
+        const uint32_t q = c - 1u - i;  // pieces behind piece i
+        const uint32_t pe = stop - q * kWalPiece;
+        const uint32_t ps = i == 0u ? start : pe - kWalPiece;
+        const uint32_t at = i == 0u ? at0 : at_rest + i - 1u;
+        ring[at % (RR * 8u)] =
+            make_uint2(blk | (q << 19) | (i == 0u ? kWalEntryFirst : 0u) | kWalEntryValid | (slot << 26), ps | ((pe - ps) << 15));
+      }
+      if (multi) {
+        slots[slot].acc = 0u;
+        lds_store(&slots[slot].remaining, c + 1u);
+      }
+    }
+    const uint32_t nfit = (uint32_t)__popcll(m_fit);
+    if (nfit) {
+      const uint32_t new_count = p_count + uni((uint32_t)__shfl((int)upto_e, (int)nfit - 1));
+      p_spans += (uint32_t)__popcll(m_fit & m_multi);
+      // rounds that are complete now go out: lane i publishes round (old count / 8) + i
+      const uint32_t r0 = p_count >> 3, r1 = new_count >> 3;
+      if ((uint32_t)lane < r1 - r0) lds_release(&seq[(r0 + lane) % RR], r0 + lane + 1u);
+      p_count = new_count;
+      p_rd += nfit;
+      if (lane == 0) {
+        lds_store(&ctl[3], r1);
+        lds_release(&ctl[5], p_rd);  // the list's places are free again: behind the reads above
+      }
+    }
+    return nfit == n ? 0 : 1;
+  };
+
+  // A checksum that does not match: counted, and the record's index inside its block - found by walking the
+  // block's headers again, this is rare - lowers the block's first_bad.
+  auto mismatch = [&](uint32_t blk, uint32_t start) {
+    atomicAdd(&p.counts[TCRC_CNT_MISMATCH], 1ull);
+    atomicMin(&p.counts[TCRC_CNT_FIRST_BAD], (unsigned long long)(p.block_base + blk));
+    const uint64_t base = (uint64_t)blk * kLogBlockBytes;
+    const uint64_t end = base + kLogBlockBytes < p.size ? base + kLogBlockBytes : p.size;
+    const bool last = p.tail && end == p.size;
+    uint32_t pos = 0, k = 0, hs = 0, ln = 0, code = 0;
+    while (pos + 6u < start && wal_step(p.img, base + pos, end, last, p.log_number, &hs, &ln, &code)) {
+      pos += hs + ln;
+      ++k;
+    }
+    atomicMin(&p.blocks[blk].first_bad, k);
+  };
+  // Walker and placer, with nothing of their own to do, take a round that is out and that nobody has claimed -
+  // never one they would have to wait for, and only while enough of them are waiting that the other waves do not
+  // run dry meanwhile.
+  auto try_claim = [&]() -> uint32_t {
+    uint32_t got = 0xffffffffu;
+    if (lane == 0) {
+      const uint32_t out = lds_load(&ctl[3]);
+      const uint32_t need = (p.tune & 2u) ? 1u : kSplitHelpMin;
+      uint32_t h = lds_load(&ctl[0]);
+      while (h + need <= out &&
+             !__hip_atomic_compare_exchange_strong(&ctl[0], &h, h + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_WORKGROUP)) {
+      }
+      if (h + need <= out) got = h;
+    }
+    return uni(got);
+  };
+
+  uint32_t spins = 0;
+  // trace: time spent in the walker's / the placer's own code, and how often they came back to it
+  unsigned long long tr_time = 0, tr_from = 0;
+  uint32_t tr_visits = 0;
+  for (;;) {
+    if (lds_load(&ctl[2])) break;  // some wave of the workgroup gave up waiting
+    uint32_t t = 0;
+    if (p.trace && wave < 2) {
+      tr_from = wall_clock64();
+      ++tr_visits;
+    }
+    if (wave == 0 && !w_done) {
+      if (!(p.tune & 4u)) __builtin_amdgcn_s_setprio(3);  // the walk is the critical path of a workgroup with little to do
+      // The header under every cursor stays in its registers while the walker is away on a round - the load that
+      // the last step issued comes back during the round - except for a lane whose record found no room: its
+      // cursor did not move, so the header under it is fetched again.
+      if (w_flags & 2u) {
+        w_flags = (w_active && w_len - w_pos >= 12u) ? 1u : 0u;
+        if (w_flags) {
+          uint2 w;
+          __builtin_memcpy(&w, w_ptr() + w_pos + 4u, 8);
+          w_hdr.lo = w.x;
+          w_hdr.hi = w.y;
+        }
+      }
+      bool blocked = false;
+      uint32_t steps = 0;
+      do {
+        blocked = walk_step();
+      } while (!blocked && !w_done && ((++steps & 31u) != 0u || !lds_load(&ctl[2])));  // the give-up flag: a look every 32 steps
+      __builtin_amdgcn_s_setprio(0);
+      if (p.trace) tr_time += wall_clock64() - tr_from;
+      if (!blocked) {
+        if (w_done) stamp(2, 0);
+        continue;
+      }
+      t = try_claim();
+      if (t == 0xffffffffu) {
+        __builtin_amdgcn_s_sleep(4);
+        if (++spins > kWalSpinLimit) lds_store(&ctl[2], 1u);
+        continue;
+      }
+    } else if (wave == 1 && !p_done) {
+      if (!(p.tune & 4u)) __builtin_amdgcn_s_setprio(2);
+      int st = 0;
+      do {
+        st = place_step();
+      } while (st == 0 && !p_done && !lds_load(&ctl[2]));
+      __builtin_amdgcn_s_setprio(0);
+      if (p.trace) tr_time += wall_clock64() - tr_from;
+      if (p_done) {
+        stamp(3, 64);
+        continue;
+      }
+      if (st == 0) continue;
+      t = try_claim();
+      if (t == 0xffffffffu) {
+        if (st == 2) __builtin_amdgcn_s_sleep(1);  // an empty list is looked at again soon
+        else __builtin_amdgcn_s_sleep(4);
+        if (++spins > kWalSpinLimit) lds_store(&ctl[2], 1u);
+        continue;
+      }
+    } else {
+      if (lane == 0) t = atomicAdd(&ctl[0], 1u);
+      t = uni(t);
+      bool over = false;
+      for (;;) {
+        const uint32_t sq = uni(lds_acquire(&seq[t % RR]));
+        if (sq == t + 1u) break;
+        const uint32_t total = uni(lds_load(&ctl[1]));
+        if (t >= total || lds_load(&ctl[2])) {
+          over = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > kWalSpinLimit) {
+          lds_store(&ctl[2], 1u);
+          over = true;
+          break;
+        }
+      }
+      if (over) break;
+    }
+    spins = 0;
+    // round t: the entries are copied out, and the round is handed back to the placer
+    const uint2 e = ring[(t % RR) * 8u + grp];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every lane has its entry before the round is given away
+    if (lane == 0) lds_release(&seq[t % RR], t + RR);
+    const bool valid = (e.x & kWalEntryValid) != 0u;
+    const bool first = (e.x & kWalEntryFirst) != 0u;
+    const uint32_t blk = e.x & 0x7ffffu, q = (e.x >> 19) & 31u, slot = e.x >> 26;
+    const uint32_t start = e.y & 0x7fffu, len = e.y >> 15;
+    const uint8_t* ptr = p.img + (uint64_t)blk * kLogBlockBytes + start;
+    // the stored value is fetched now so its latency hides behind the row loop
+    uint32_t stored = 0;
+    if (valid && first && j == G - 1) __builtin_memcpy(&stored, ptr - 6, 4);
+    const uint32_t core = span_remainder<G, NT>(lds, LB, lane, ptr, len, first ? 0u : 0xffffffffu, valid,
+                                                (const uint8_t*)p.tab_main);
+    // a piece with q pieces behind it enters its span's remainder multiplied by x^(8 * kWalPiece * q), on four
+    // lanes of the group (see k_wal_fused)
+    uint32_t shifted = core;
+    if (__any(valid && q != 0u)) {
+      const uint32_t rr = __shfl(core, lane | (G - 1));
+      const int l = j & 3;
+      uint32_t b = pow_piece[(q & 15u) * 4u + (uint32_t)l];
+      uint32_t part = 0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        part ^= ((rr >> (31 - 8 * l - k)) & 1u) ? b : 0u;
+        b = (b >> 1) ^ ((b & 1u) ? 0x82f63b78u : 0u);
+      }
+      part ^= __shfl_xor(part, 1);
+      part ^= __shfl_xor(part, 2);
+      if (q != 0u) shifted = part;
+    }
+    if (valid && j == G - 1) {
+      if (slot == kWalNoSlot) {
+        const uint32_t crc = ~core;
+        if (stored != ((crc >> 15) | (crc << 17)) + kMaskDelta) mismatch(blk, start);
+      } else {
+        WalSlot* sl = &slots[slot];
+        if (first) {
+          lds_store(&sl->stored, stored);
+          lds_store(&sl->blk, blk);
+          lds_store(&sl->start, start);
+        }
+        (void)__hip_atomic_fetch_xor(&sl->acc, shifted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // release what this piece left in the slot, acquire what the others left
+        const uint32_t before = __hip_atomic_fetch_sub(&sl->remaining, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (before == 2u) {  // the last piece: compare, then give the slot back
+          const uint32_t crc = ~lds_load(&sl->acc);
+          const uint32_t want = lds_load(&sl->stored);
+          const uint32_t sblk = lds_load(&sl->blk), sstart = lds_load(&sl->start);
+          lds_release(&sl->remaining, 0u);
+          if (want != ((crc >> 15) | (crc << 17)) + kMaskDelta) mismatch(sblk, sstart);
+        }
+      }
+    }
+  }
+  stamp(31, 0);
+  if (p.trace && wave < 2 && lane == 0) {
+    p.trace[blockIdx.x * 32u + 4u + wave] = tr_time + 1ull;  // +1: zero means "not written" to the reader
+    p.trace[blockIdx.x * 32u + 6u + wave] = tr_visits + 1ull;
+  }
+  if (wave == 0) {
+    uint32_t total = w_records;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) total += __shfl_xor(total, o);
+    if (lane == 0) {
+      if (total) atomicAdd(&p.counts[TCRC_CNT_CHECKED], (unsigned long long)total);
+      if (lds_load(&ctl[2])) atomicAdd(&p.counts[TCRC_CNT_MISMATCH], 1ull << 62);  // a wait ran out: say so loudly
+      if (p.records_host) {
+        // the launch's record count goes to the host without a copy command (see k_wal_fused)
+        unsigned long long* w = p.launch_words;
+        (void)__hip_atomic_fetch_add(w, (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long before = __hip_atomic_fetch_add(w + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (before + 1ull == (unsigned long long)gridDim.x) {
+          const unsigned long long sum = __hip_atomic_exchange(w, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          (void)__hip_atomic_exchange(w + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          *p.records_host += sum;
+        }
+      }
+    }
+  }
+}
 
 // ---- log framing ---------------------------------------------------------------------------------------
 // One launch writes a log image the way log::Writer::AddRecord / EmitPhysicalRecord append records
@@ -1531,16 +2103,24 @@ int run_wal_scan(tcrc_ctx* ctx, WalScanParams p, void* stream) {
   p.tab_aux = ctx->d_tab_aux[gi];
   memcpy(p.pow_piece, wal_piece_powers(), sizeof(p.pow_piece));
   p.trace = (unsigned long long*)ctx->wal_trace;
+  p.sort_classes = ctx->wal_sort ? 1u : 0u;
+  p.tune = ctx->wal_tune;
   // chunks of up to 64 blocks (one per walker lane), at least two chunks per workgroup
   p.chunk_shift = 6;
   while (p.chunk_shift > 0 && (p.nblocks >> p.chunk_shift) < 2u * (uint32_t)ctx->cus) --p.chunk_shift;
   if (ctx->forced_wal_chunk_shift >= 0) p.chunk_shift = (uint32_t)ctx->forced_wal_chunk_shift;
   const unsigned wgs = p.nblocks < (uint32_t)ctx->cus ? p.nblocks : (unsigned)ctx->cus;
   hipStream_t s = (hipStream_t)stream;
-  if (ctx->nontemporal)
+  if (ctx->wal_split) {
+    if (ctx->nontemporal)
+      hipLaunchKernelGGL(k_wal_split<true>, dim3(wgs), dim3(kThreads), 0, s, p);
+    else
+      hipLaunchKernelGGL(k_wal_split<false>, dim3(wgs), dim3(kThreads), 0, s, p);
+  } else if (ctx->nontemporal) {
     hipLaunchKernelGGL(k_wal_fused<true>, dim3(wgs), dim3(kThreads), 0, s, p);
-  else
+  } else {
     hipLaunchKernelGGL(k_wal_fused<false>, dim3(wgs), dim3(kThreads), 0, s, p);
+  }
   HIP_TRY(hipGetLastError());
   return TCRC_OK;
 }
@@ -1677,6 +2257,9 @@ int tcrc_init(int device, tcrc_ctx** out) {
       return fail(TCRC_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
     }
   }
+  if (const char* e = getenv("TCRC_WAL_SPLIT")) ctx->wal_split = atoi(e) != 0;
+  if (const char* e = getenv("TCRC_WAL_SORT")) ctx->wal_sort = atoi(e) != 0;
+  if (const char* e = getenv("TCRC_WAL_TUNE")) ctx->wal_tune = (uint32_t)atoi(e);
   if (const char* e = getenv("TCRC_FRAME_PHASE")) ctx->frame_phase_dst = atoi(e) != 0;
   if (int rc = long_device_setup(ctx)) {
     tcrc_shutdown(ctx);

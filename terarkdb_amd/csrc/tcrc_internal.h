@@ -164,6 +164,8 @@ struct WalScanParams {
   uint32_t nblocks;
   uint32_t tail;               // the slice ends where the file ends
   uint32_t chunk_shift;        // log2 of the blocks per chunk dealt to a workgroup at a time
+  uint32_t tune;               // development aid, normally 0
+  uint32_t sort_classes;       // k_wal_split: entries of a placer step go into the ring by length class
   tcrc_wal_block* blocks;      // [nblocks]
   unsigned long long* counts;  // the caller's TCRC_CNT_* block (accumulated into)
   unsigned long long* records_host;  // when not NULL: the launch's candidate records are added to this word of
@@ -322,6 +324,9 @@ struct tcrc_ctx {
   int cus = 0;
   int forced_g = 0;
   int forced_wal_chunk_shift = -1;  // >= 0: set for experiments only (TCRC_WAL_CHUNK_SHIFT)
+  uint32_t wal_tune = 0;  // development aid (TCRC_WAL_TUNE): bits that switch parts of k_wal_split off
+  bool wal_sort = true;   // the placer lays a step's entries down by length class (TCRC_WAL_SORT=0: in list order)
+  bool wal_split = true;  // log scan with walker and placer apart (TCRC_WAL_SPLIT=0: the one-wave walker)
   bool nontemporal = true;  // batch data is read once: keep it from displacing other lines in L2/MALL
   uint32_t* d_tab_main[tcrc_internal::kGeoCount] = {};
   uint32_t* d_tab_aux[tcrc_internal::kGeoCount] = {};

@@ -36,13 +36,22 @@ capi.lib.tcrc_debug_wal_trace(eng.ctx, None)
 t = trace.cpu().numpy().reshape(256, 32).astype(np.float64)
 t0 = t[:, 0].min()
 us = np.where(t > 0, (t - t0) / 100.0, np.nan)
-names = {0: "start", 1: "tables in place", 2: "walk over", 31: "end"}
+names = {0: "start", 1: "tables in place", 2: "walk over", 3: "all placed", 31: "end"}
 print("event: min / median / max over workgroups (us since first start)")
-for k in range(32):
+for k in (0, 1, 2, 3, 31):
     col = us[:, k]
     if np.isnan(col).all():
         continue
     print(f"{names.get(k, str(k)):18s} {np.nanmin(col):7.1f} {np.nanmedian(col):7.1f} {np.nanmax(col):7.1f}   ({int((~np.isnan(col)).sum())} wgs)")
+raw = trace.cpu().numpy().reshape(256, 32).astype(np.float64)
+for k, nm in ((4, "walker's own code, us"), (5, "placer's own code, us")):
+    if raw[:, k].any():
+        v = (raw[:, k] - 1) / 100.0
+        print(f"{nm:24s} min/median/max {v.min():7.1f} {np.median(v):7.1f} {v.max():7.1f}   sum over workgroups {v.sum():9.0f}")
+for k, nm in ((6, "walker visits"), (7, "placer visits")):
+    if raw[:, k].any():
+        v = raw[:, k] - 1
+        print(f"{nm:24s} min/median/max {v.min():7.0f} {np.median(v):7.0f} {v.max():7.0f}")
 if len(sys.argv) > 2:
     np.save(sys.argv[2], us)
     order = np.argsort(us[:, 31])
