@@ -1100,15 +1100,9 @@ __global__ __launch_bounds__(kThreads) void k_wal_fused(WalScanParams p) {
   };
 
   uint32_t spins = 0;
-  unsigned long long tr_time = 0, tr_from = 0;  // trace: time in the walker's own code, and its visits
-  uint32_t tr_visits = 0;
   for (;;) {
     if (lds_load(&ctl[2])) break;  // some wave of the workgroup gave up waiting
     uint32_t t = 0;
-    if (p.trace && wave == 0 && !w_done) {
-      tr_from = wall_clock64();
-      ++tr_visits;
-    }
     if (wave == 0 && !w_done) {
       __builtin_amdgcn_s_setprio(3);  // the walk is the critical path of a workgroup with little to do
       // The walker.  While its records find room it only walks; when they do not, it takes a round itself if one
@@ -1120,7 +1114,6 @@ __global__ __launch_bounds__(kThreads) void k_wal_fused(WalScanParams p) {
       do {
         blocked = walk_step(hdr);
       } while (!blocked && !w_done && !lds_load(&ctl[2]));
-      if (p.trace) tr_time += wall_clock64() - tr_from;
       if (!blocked) {
         if (w_done) {
           stamp(2);
@@ -1228,10 +1221,6 @@ __global__ __launch_bounds__(kThreads) void k_wal_fused(WalScanParams p) {
     }
   }
   stamp(31);
-  if (p.trace && tid == 0) {
-    p.trace[blockIdx.x * 32u + 4u] = tr_time + 1ull;
-    p.trace[blockIdx.x * 32u + 6u] = tr_visits + 1ull;
-  }
   if (wave == 0) {
     uint32_t total = w_records;
 #pragma unroll
@@ -1267,7 +1256,7 @@ __global__ __launch_bounds__(kThreads) void k_wal_fused(WalScanParams p) {
 // 64 entries of that list per step - parallel over records, no header chain in its way - and does what is left:
 // piece counts, places in the ring from ballots, slots for spans of several pieces, the ring writes.  Both go on
 // to checksum rounds like the other fourteen waves when they have nothing else to do.
-constexpr uint32_t kSplitRingRounds = 144;   // rounds of 8 entries in the ring (9 KiB)
+constexpr uint32_t kSplitRingRounds = 136;   // rounds of 8 entries in the ring (8.5 KiB)
 constexpr uint32_t kSplitListEntries = 256;  // spans the walker may be ahead of the placer (2 KiB)
 constexpr uint32_t kSplitHelpMin = 12;       // walker and placer take a round themselves only with this many waiting
 // Small records: how far in front of the walker's cursor the placer asks for the image's 64-byte sectors, up to
@@ -1276,7 +1265,9 @@ constexpr uint32_t kSplitAhead = 1024, kSplitAheadSpan = 640, kSplitAheadBacklog
 // classes of pieces that share rounds: longer than kSplitLong bytes, longer than kSplitShort, and the rest
 constexpr uint32_t kSplitLong = 1024, kSplitShort = 256;
 
-template <bool NT>
+// TRACE: the instantiation that writes phase timestamps (development aid; the time stamps' registers are enough to
+// change how the compiler schedules the checksum loops, so the ordinary instantiation has none)
+template <bool NT, bool TRACE>
 __global__ __launch_bounds__(kThreads) void k_wal_split(WalScanParams p) {
   constexpr int G = 8;
   constexpr int kAuxDwords = AuxDwords<G>::value;
@@ -1287,15 +1278,27 @@ __global__ __launch_bounds__(kThreads) void k_wal_split(WalScanParams p) {
   __shared__ uint2 rlist[kSplitListEntries];
   __shared__ WalSlot slots[kWalSlots];
   // [0] next ticket, [1] rounds in all once everything is placed (till then ~0), [2] set when a wait ran out,
-  // [3] rounds that are out, [4] spans the walker has listed (bit 31: and the walk is over), [5] spans the placer has taken
+  // [3] rounds that are out, [4] spans the walker has listed (bit 31: and the walk is over), [5] spans the placer has taken,
+  // [6] candidate records of the blocks walked so far
   __shared__ uint32_t ctl[8];
   __shared__ uint32_t pow_piece[64];  // [q * 4 + l]: x^(8 * kWalPiece * q) * x^(8 l)
   __shared__ uint32_t ahead_sink[64];  // where the sectors asked for ahead of the walker land (never read)
+  // The walker's cursors and counters (wave 0) and the placer's counters (wave 1) while those waves are away on a
+  // round: kept here and not in registers, so that the checksum code of all sixteen waves has the registers to
+  // itself (with them live across it, the compiler schedules the row loop's table lookups four at a time instead
+  // of sixteen, and a scan that waits for its checksums is 3 % slower).
+  __shared__ uint4 w_save[64];
+  __shared__ uint32_t u_save[8];
 
   const int tid = threadIdx.x;
   // trace (development aid): [0] start, [1] tables in place, [2] walk over, [3] everything placed, [31] end of wave 0
   auto stamp = [&](uint32_t at, int who) {
-    if (p.trace && tid == who && at < 32u) p.trace[blockIdx.x * 32u + at] = wall_clock64();
+    if constexpr (TRACE) {
+      if (p.trace && tid == who && at < 32u) p.trace[blockIdx.x * 32u + at] = wall_clock64();
+    } else {
+      (void)at;
+      (void)who;
+    }
   };
   stamp(0, 0);
   fill_main_tables(lds, p.tab_main, tid);
@@ -1305,6 +1308,8 @@ __global__ __launch_bounds__(kThreads) void k_wal_split(WalScanParams p) {
   for (int i = tid; i < kWalSlots; i += kThreads) slots[i].remaining = 0u;
   if (tid < 64) pow_piece[tid] = p.pow_piece[tid];
   if (tid < 8) ctl[tid] = tid == 1 ? 0xffffffffu : 0u;
+  if (tid < 64) w_save[tid] = make_uint4(0u, 0u, 0u, 0u);
+  if (tid < 8) u_save[tid] = tid == 2 ? kSplitListEntries : 0u;
   __syncthreads();
   stamp(1, 0);
 
@@ -1336,15 +1341,15 @@ __global__ __launch_bounds__(kThreads) void k_wal_split(WalScanParams p) {
 
   // ---- the walker (wave 0): every lane chases the headers of one block at a time
   uint32_t w_next = 0;  // next number to hand to an idle lane (the same in every lane)
-  uint32_t w_blk = 0, w_pos = 0, w_k = 0, w_records = 0;
+  uint32_t w_blk = 0, w_pos = 0, w_k = 0;
   uint32_t w_len = 0;          // bytes of the lane's block that are in the image (32768 but for the image's last block)
   auto w_ptr = [&]() -> const uint8_t* { return p.img + (uint64_t)w_blk * kLogBlockBytes; };  // the block's first byte
   bool w_active = false, w_done = false;
   // bit 0: w_hdr holds header bytes 4..11 under the cursor, fetched with one 8-byte load (>= 12 bytes were left);
-  // bit 1: the lane's record found no room in the list, so w_hdr is not the header under its cursor
+  // bit 1: w_hdr is not the header under the lane's cursor (its record found no room in the list, or the walker
+  // has been away on a round: the header registers do not live across one)
   // (one word on purpose: two flags set in the two arms of a branch end up in memory, behind a selected address)
   uint32_t w_flags = 0;
-  WalHeader w_hdr = {0u, 0u};
   uint32_t l_wr = 0;                     // spans listed so far (the same in every lane)
   uint32_t l_room = kSplitListEntries;   // places in the list known to be free
   const uint32_t ln32 = (uint32_t)p.log_number;
@@ -1355,7 +1360,7 @@ __global__ __launch_bounds__(kThreads) void k_wal_split(WalScanParams p) {
   // db/log_reader.cc:317-384 - is decoded without a branch, in 32-bit arithmetic relative to the block; whatever
   // else a lane meets (the last bytes of a block, a header that ends the block's walk) takes the general
   // wal_fetch / wal_decode, which the whole wave then steps through once.
-  auto walk_step = [&]() -> bool {
+  auto walk_step = [&](WalHeader& w_hdr) -> bool {
     WalHeader hdr = w_hdr;
     const unsigned long long idle = __ballot(!w_active);
     if (idle && w_next < b_hi) {
@@ -1407,7 +1412,7 @@ __global__ __launch_bounds__(kThreads) void k_wal_split(WalScanParams p) {
           b->n_records = w_k;
           b->end_offset = w_pos;
           b->end_code = code;
-          w_records += w_k;
+          atomicAdd(&ctl[6], w_k);  // the workgroup's candidate records
           w_active = false;
         }
       }
@@ -1432,8 +1437,6 @@ __global__ __launch_bounds__(kThreads) void k_wal_split(WalScanParams p) {
       w_pos = npos;
       ++w_k;
       w_flags = fastn ? 1u : 0u;
-    } else if (ok) {
-      w_flags |= 2u;
     }
     // Unconditionally, so that the load is waited for where the next step decodes it and not here: a lane whose
     // record found no room ends the walk loop (the step returns true) and fetches its header again when the
@@ -1654,40 +1657,46 @@ __global__ __launch_bounds__(kThreads) void k_wal_split(WalScanParams p) {
   };
 
   uint32_t spins = 0;
-  // trace: time spent in the walker's / the placer's own code, and how often they came back to it
-  unsigned long long tr_time = 0, tr_from = 0;
-  uint32_t tr_visits = 0;
   for (;;) {
     if (lds_load(&ctl[2])) break;  // some wave of the workgroup gave up waiting
     uint32_t t = 0;
-    if (p.trace && wave < 2) {
-      tr_from = wall_clock64();
-      ++tr_visits;
-    }
     if (wave == 0 && !w_done) {
       if (!(p.tune & 4u)) __builtin_amdgcn_s_setprio(3);  // the walk is the critical path of a workgroup with little to do
-      // The header under every cursor stays in its registers while the walker is away on a round - the load that
-      // the last step issued comes back during the round - except for a lane whose record found no room: its
-      // cursor did not move, so the header under it is fetched again.
-      if (w_flags & 2u) {
-        w_flags = (w_active && w_len - w_pos >= 12u) ? 1u : 0u;
-        if (w_flags) {
-          uint2 w;
-          __builtin_memcpy(&w, w_ptr() + w_pos + 4u, 8);
-          w_hdr.lo = w.x;
-          w_hdr.hi = w.y;
-        }
+      // the walker's cursors and counters come out of LDS (see w_save), and the header under every cursor is fetched
+      {
+        const uint4 sv = w_save[lane];
+        w_blk = sv.x & 0x7fffffffu;
+        w_active = (sv.x >> 31) != 0u;
+        w_pos = sv.y;
+        w_k = sv.z;
+        w_len = sv.w;
+        w_next = uni(u_save[0]);
+        l_wr = uni(u_save[1]);
+        l_room = uni(u_save[2]);
+      }
+      WalHeader w_hdr = {0u, 0u};
+      w_flags = (w_active && w_len - w_pos >= 12u) ? 1u : 0u;
+      if (w_flags) {
+        uint2 w;
+        __builtin_memcpy(&w, w_ptr() + w_pos + 4u, 8);
+        w_hdr.lo = w.x;
+        w_hdr.hi = w.y;
       }
       bool blocked = false;
       uint32_t steps = 0;
       do {
-        blocked = walk_step();
+        blocked = walk_step(w_hdr);
       } while (!blocked && !w_done && ((++steps & 31u) != 0u || !lds_load(&ctl[2])));  // the give-up flag: a look every 32 steps
       __builtin_amdgcn_s_setprio(0);
-      if (p.trace) tr_time += wall_clock64() - tr_from;
       if (!blocked) {
         if (w_done) stamp(2, 0);
         continue;
+      }
+      w_save[lane] = make_uint4(w_blk | (w_active ? 0x80000000u : 0u), w_pos, w_k, w_len);
+      if (lane == 0) {
+        u_save[0] = w_next;
+        u_save[1] = l_wr;
+        u_save[2] = l_room;
       }
       t = try_claim();
       if (t == 0xffffffffu) {
@@ -1697,17 +1706,26 @@ __global__ __launch_bounds__(kThreads) void k_wal_split(WalScanParams p) {
       }
     } else if (wave == 1 && !p_done) {
       if (!(p.tune & 4u)) __builtin_amdgcn_s_setprio(2);
+      p_rd = uni(u_save[4]);
+      p_count = uni(u_save[5]);
+      p_open = uni(u_save[6]);
+      p_spans = uni(u_save[7]);
       int st = 0;
       do {
         st = place_step();
       } while (st == 0 && !p_done && !lds_load(&ctl[2]));
       __builtin_amdgcn_s_setprio(0);
-      if (p.trace) tr_time += wall_clock64() - tr_from;
       if (p_done) {
         stamp(3, 64);
         continue;
       }
       if (st == 0) continue;
+      if (lane == 0) {
+        u_save[4] = p_rd;
+        u_save[5] = p_count;
+        u_save[6] = p_open;
+        u_save[7] = p_spans;
+      }
       t = try_claim();
       if (t == 0xffffffffu) {
         if (st == 2) __builtin_amdgcn_s_sleep(1);  // an empty list is looked at again soon
@@ -1793,14 +1811,8 @@ __global__ __launch_bounds__(kThreads) void k_wal_split(WalScanParams p) {
     }
   }
   stamp(31, 0);
-  if (p.trace && wave < 2 && lane == 0) {
-    p.trace[blockIdx.x * 32u + 4u + wave] = tr_time + 1ull;  // +1: zero means "not written" to the reader
-    p.trace[blockIdx.x * 32u + 6u + wave] = tr_visits + 1ull;
-  }
   if (wave == 0) {
-    uint32_t total = w_records;
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) total += __shfl_xor(total, o);
+    const uint32_t total = lds_load(&ctl[6]);  // complete: wave 0 wrote it itself
     if (lane == 0) {
       if (total) atomicAdd(&p.counts[TCRC_CNT_CHECKED], (unsigned long long)total);
       if (lds_load(&ctl[2])) atomicAdd(&p.counts[TCRC_CNT_MISMATCH], 1ull << 62);  // a wait ran out: say so loudly
@@ -2112,10 +2124,12 @@ int run_wal_scan(tcrc_ctx* ctx, WalScanParams p, void* stream) {
   const unsigned wgs = p.nblocks < (uint32_t)ctx->cus ? p.nblocks : (unsigned)ctx->cus;
   hipStream_t s = (hipStream_t)stream;
   if (ctx->wal_split) {
-    if (ctx->nontemporal)
-      hipLaunchKernelGGL(k_wal_split<true>, dim3(wgs), dim3(kThreads), 0, s, p);
+    if (p.trace)
+      hipLaunchKernelGGL((k_wal_split<true, true>), dim3(wgs), dim3(kThreads), 0, s, p);
+    else if (ctx->nontemporal)
+      hipLaunchKernelGGL((k_wal_split<true, false>), dim3(wgs), dim3(kThreads), 0, s, p);
     else
-      hipLaunchKernelGGL(k_wal_split<false>, dim3(wgs), dim3(kThreads), 0, s, p);
+      hipLaunchKernelGGL((k_wal_split<false, false>), dim3(wgs), dim3(kThreads), 0, s, p);
   } else if (ctx->nontemporal) {
     hipLaunchKernelGGL(k_wal_fused<true>, dim3(wgs), dim3(kThreads), 0, s, p);
   } else {
