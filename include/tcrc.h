@@ -272,6 +272,13 @@ int tcrc_host_batch_stamp(tcrc_ctx* ctx, const void* h_base, uint64_t base_bytes
                           const uint8_t* h_suffix, uint32_t flags, uint32_t* h_out);
 int tcrc_host_blocks_stamp(tcrc_ctx* ctx, const void* h_base, uint64_t n_blocks, uint32_t block_len, uint64_t stride,
                            uint32_t init, int suffix_byte, uint32_t flags, uint32_t* h_out);
+/* Host form of tcrc_dev_blocks_verify (BlockFetcher::CheckBlockChecksum, table/block_fetcher.cc:36-71, over an
+ * extent of equally spaced blocks as read from a file): stored values from h_expected[i], or with
+ * TCRC_F_EXPECT_AFTER from the image, right behind every block (behind its suffix byte when one is given - the
+ * image then extends 4 or 5 bytes beyond the last block).  h_out / h_ok may be NULL. */
+int tcrc_host_blocks_verify(tcrc_ctx* ctx, const void* h_base, uint64_t n_blocks, uint32_t block_len, uint64_t stride,
+                            uint32_t init, int suffix_byte, uint32_t flags, const uint32_t* h_expected, uint32_t* h_out,
+                            uint8_t* h_ok, uint64_t* h_counts);
 /* h_counts: 3 x uint64 (TCRC_CNT_*), filled by the call. */
 int tcrc_host_batch_verify(tcrc_ctx* ctx, const void* h_base, uint64_t base_bytes, const tcrc_desc* h_desc, uint64_t n,
                            const uint8_t* h_suffix, uint32_t flags, const uint32_t* h_expected, uint32_t* h_out,
@@ -317,6 +324,52 @@ typedef uint32_t (*tcrc_extend_fn)(uint32_t init, const char* data, size_t n);
 uint32_t tcrc_crc32c_extend(uint32_t init, const char* data, size_t n);
 void tcrc_set_scalar_fallback(tcrc_extend_fn fn);
 uint64_t tcrc_scalar_fallback_calls(void);
+
+/* ---- several GPUs ----------------------------------------------------------------------- */
+/* The path shards by units that carry their own checksums (SST blocks, 32 KiB log blocks, files), so a
+ * verification corpus splits into contiguous ranges that are verified independently; what comes together at the
+ * end is three counters.  The loop this parallelises is DBImpl::VerifyChecksum (db/db_impl.cc:4657-4690: one
+ * table file after the other) over BlockBasedTable::VerifyChecksumInBlocks
+ * (table/block_based_table_reader.cc:2647-2695: one block after the other); the reference has no counterpart
+ * of the entry points themselves (it is one host thread).
+ *
+ * Contiguous range [*lo, *hi) of unit `index` of `count` shards of n_units (sizes differ by at most one). */
+void tcrc_shard_range(uint64_t n_units, uint32_t index, uint32_t count, uint64_t* lo, uint64_t* hi);
+
+/* One process, several GPUs: a group owns one context and one stream per member; devices[i] is member i's GPU
+ * (a GPU may be named more than once).  A group call runs every member's shard on a host thread of its own and
+ * reduces {mismatches, first bad, checked} on the host - no collective. */
+typedef struct tcrc_group tcrc_group;
+int tcrc_group_init(const int* devices, int n, tcrc_group** out);
+int tcrc_group_shutdown(tcrc_group* g);
+int tcrc_group_size(const tcrc_group* g);
+tcrc_ctx* tcrc_group_ctx(tcrc_group* g, int member); /* for the single-context entry points, e.g. to fill a shard */
+int tcrc_group_device(const tcrc_group* g, int member);
+/* Uniform blocks resident on the members' GPUs: member m holds the blocks tcrc_shard_range(n_blocks, m, members) of
+ * the corpus at d_bases[m] (and their stored values at d_expected[m], unless TCRC_F_EXPECT_AFTER).  h_counts
+ * (3 x uint64) receives the corpus's totals; TCRC_CNT_FIRST_BAD is a block index of the corpus.  Returns when
+ * every member is done. */
+int tcrc_group_dev_blocks_verify(tcrc_group* g, const void* const* d_bases, uint64_t n_blocks, uint32_t block_len,
+                                 uint64_t stride, uint32_t init, int suffix_byte, uint32_t flags,
+                                 const uint32_t* const* d_expected, uint64_t* h_counts);
+/* The same for one image in host memory: every member uploads and verifies its range (the host link of every
+ * GPU works at once). */
+int tcrc_group_host_blocks_verify(tcrc_group* g, const void* h_base, uint64_t n_blocks, uint32_t block_len,
+                                  uint64_t stride, uint32_t init, int suffix_byte, uint32_t flags,
+                                  const uint32_t* h_expected, uint8_t* h_ok, uint64_t* h_counts);
+
+/* One process per GPU: the ranks' only exchange.  d_counts is the rank's TCRC_CNT_* block on its GPU, counted in
+ * the rank's own numbering; first_unit_of_rank is the corpus index of the rank's first unit.  Enqueues on
+ * `stream`: ncclAllReduce(ncclSum) over {mismatches, checked} and ncclAllReduce(ncclMin) over the first bad unit's
+ * corpus index, in place, on the caller's communicator (an ncclComm_t passed as void*) - every rank's block then
+ * holds the corpus's totals.  librccl is opened at the first of these calls (the copy already loaded into the
+ * process, if there is one), so libtcrc.so itself does not depend on it.
+ * The three helpers let a caller without RCCL headers make the communicator: rank 0 gets the 128-byte id and
+ * hands it to the others by whatever means the processes share (a file, MPI, a key-value store). */
+int tcrc_rccl_get_unique_id(void* id128);
+int tcrc_rccl_comm_init_rank(tcrc_ctx* ctx, int nranks, const void* id128, int rank, void** comm_out);
+int tcrc_rccl_comm_destroy(void* comm);
+int tcrc_rccl_allreduce_counts(tcrc_ctx* ctx, void* comm, uint64_t* d_counts, uint64_t first_unit_of_rank, void* stream);
 
 /* ---- measurement aid ----------------------------------------------------------- */
 /* Streams nbytes from d_base with loads only (no checksum work) so a benchmark can report

@@ -152,6 +152,13 @@ int tcrc_shim_wal_verify_file(tcrc_ctx* ctx, const char* path, uint64_t log_numb
 int tcrc_shim_verify_db(tcrc_ctx* ctx, const char* dir, uint32_t shard_index, uint32_t shard_count, uint64_t* report_out,
                         char* message, size_t message_cap, char* bad_file, size_t bad_file_cap);
 
+/* The same over a group of GPUs in one process (tcrc_group_init, tcrc.h): member m verifies shard m of the
+ * directory's files on a host thread of its own; the report adds up, and of several failing tables the status
+ * is that of the one with the smallest file number.  DBImpl::VerifyChecksum (db/db_impl.cc:4657-4690) spread
+ * over the GPUs of one machine. */
+int tcrc_shim_verify_db_group(tcrc_group* group, const char* dir, uint64_t* report_out, char* message, size_t message_cap,
+                              char* bad_file, size_t bad_file_cap);
+
 /* Whole-file crc32c as the backup engine computes it (utilities/backupable/backupable_db.cc:1414-1452
  * CalculateChecksum; :1195-1283 CopyOrCreateFile): size_limit 0 = whole file; buffer_size 0 = default.
  * Return 0, or -1 with the Status text in message (if not NULL). */

@@ -83,6 +83,19 @@ SIGNATURES.update({
     "tcrc_dev_wal_frame_enqueue": (_i, [_vp, _vp, _vp, _vp, _u64, _vp]),
     "tcrc_dev_wal_list": (_i, [_vp, _vp, _u64, _u64, _vp, _vp, _u64, C.POINTER(_u64), _vp]),
     "tcrc_host_wal_list": (_i, [_vp, _vp, _u64, _u64, _vp, _vp, _u64, C.POINTER(_u64)]),
+    "tcrc_host_blocks_verify": (_i, [_vp, _vp, _u64, _u32, _u64, _u32, _i, _u32, _vp, _vp, _vp, _vp]),
+    "tcrc_shard_range": (None, [_u64, _u32, _u32, C.POINTER(_u64), C.POINTER(_u64)]),
+    "tcrc_group_init": (_i, [C.POINTER(_i), _i, C.POINTER(_vp)]),
+    "tcrc_group_shutdown": (_i, [_vp]),
+    "tcrc_group_size": (_i, [_vp]),
+    "tcrc_group_ctx": (_vp, [_vp, _i]),
+    "tcrc_group_device": (_i, [_vp, _i]),
+    "tcrc_group_dev_blocks_verify": (_i, [_vp, C.POINTER(_vp), _u64, _u32, _u64, _u32, _i, _u32, C.POINTER(_vp), _vp]),
+    "tcrc_group_host_blocks_verify": (_i, [_vp, _vp, _u64, _u32, _u64, _u32, _i, _u32, _vp, _vp, _vp]),
+    "tcrc_rccl_get_unique_id": (_i, [_vp]),
+    "tcrc_rccl_comm_init_rank": (_i, [_vp, _i, _vp, _i, C.POINTER(_vp)]),
+    "tcrc_rccl_comm_destroy": (_i, [_vp]),
+    "tcrc_rccl_allreduce_counts": (_i, [_vp, _vp, _vp, _u64, _vp]),
     "tcrc_get_stats": (_i, [_vp, C.POINTER(Stats)]),
     "tcrc_reset_stats": (_i, [_vp]),
     "tcrc_debug_tables": (_i, [_i, _vp, _vp, _sz, C.POINTER(_sz)]),
@@ -138,6 +151,7 @@ SIGNATURES.update({
     "tcrc_shim_cache_records_check": (_i, [_vp, _vp, _sz, _vp, _vp, _sz, _vp]),
     "tcrc_shim_wal_verify_file": (_i, [_vp, C.c_char_p, _u64, _sz, _i, _vp, _sz, _vp, C.c_char_p, _sz]),
     "tcrc_shim_verify_db": (_i, [_vp, C.c_char_p, _u32, _u32, C.POINTER(_u64), C.c_char_p, _sz, C.c_char_p, _sz]),
+    "tcrc_shim_verify_db_group": (_i, [_vp, C.c_char_p, C.POINTER(_u64), C.c_char_p, _sz, C.c_char_p, _sz]),
     "tcrc_shim_file_checksum": (_i, [_vp, C.c_char_p, _u64, _sz, C.POINTER(_u32), C.POINTER(_u64), C.c_char_p, _sz]),
     "tcrc_shim_copy_file": (_i, [_vp, C.c_char_p, C.c_char_p, _u64, _sz, _i, C.POINTER(_u32), C.POINTER(_u64),
                                  C.c_char_p, _sz]),

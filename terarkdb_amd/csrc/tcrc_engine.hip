@@ -1514,8 +1514,9 @@ __global__ __launch_bounds__(kThreads) void k_wal_split(WalScanParams p) {
         const uint32_t blen = (uint32_t)(block_end(blk) - bbase);
         const uint32_t lim = blen >= 4u ? ((blen - 4u) >> 6) + 1u : 0u;  // sectors of the block that hold four readable bytes
         // sectors reached so far: up to (header position + kSplitAhead) / 64; a block's first record starts from nothing
-        const uint32_t from = start == 6u ? 0u : ((start - 6u + kSplitAhead) >> 6) + 1u;
-        uint32_t to = ((start + span + kSplitAhead) >> 6) + 1u;
+        const uint32_t ahead = (p.tune >> 8) & 0xffu ? ((p.tune >> 8) & 0xffu) * 256u : kSplitAhead;
+        const uint32_t from = start == 6u ? 0u : ((start - 6u + ahead) >> 6) + 1u;
+        uint32_t to = ((start + span + ahead) >> 6) + 1u;
         if (to > lim) to = lim;
         if (to > from + 40u) to = from + 40u;
         if (!has || span > kSplitAheadSpan) to = 0u;

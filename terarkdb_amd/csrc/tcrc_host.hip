@@ -380,6 +380,52 @@ int tcrc_host_blocks_stamp(tcrc_ctx* ctx, const void* h_base, uint64_t n_blocks,
   return TCRC_OK;
 }
 
+int tcrc_host_blocks_verify(tcrc_ctx* ctx, const void* h_base, uint64_t n_blocks, uint32_t block_len, uint64_t stride,
+                            uint32_t init, int suffix_byte, uint32_t flags, const uint32_t* h_expected, uint32_t* h_out,
+                            uint8_t* h_ok, uint64_t* h_counts) {
+  if (!ctx) return fail(TCRC_ERR_INVALID, "null context");
+  if (!h_counts) return fail(TCRC_ERR_INVALID, "verify needs a counts block");
+  h_counts[TCRC_CNT_MISMATCH] = 0;
+  h_counts[TCRC_CNT_FIRST_BAD] = ~0ull;
+  h_counts[TCRC_CNT_CHECKED] = 0;
+  if (n_blocks == 0) return TCRC_OK;
+  if (!h_base) return fail(TCRC_ERR_INVALID, "null argument");
+  // the geometry is checked before anything is read from the caller's memory
+  if (block_len > (1u << 30)) return fail(TCRC_ERR_TOO_LARGE, "block_len above 1 GiB: use the long-buffer entry point");
+  if (n_blocks > 1 && stride < block_len) return fail(TCRC_ERR_INVALID, "stride smaller than block_len");
+  if (n_blocks > 1 && (n_blocks - 1) > (~0ull - block_len - 8) / stride) return fail(TCRC_ERR_INVALID, "n_blocks * stride overflows");
+  if (!h_expected && !(flags & (TCRC_F_EXPECT_AFTER | TCRC_F_EXPECT_BEFORE)))
+    return fail(TCRC_ERR_INVALID, "verify needs h_expected or an in-image expectation flag");
+  if ((flags & TCRC_F_EXPECT_BEFORE)) return fail(TCRC_ERR_INVALID, "uniform blocks keep their stored value behind them");
+  HostCallTimer timer(ctx);
+  LaneLease lease(ctx);
+  tcrc_lane* const L = lease.lane;
+  TCRC_DEVICE_SCOPE(ctx);
+  if (int rc = host_begin(L)) return rc;
+  StreamGuard guard(L->stream);  // an error return must not leave copies from the caller's memory in flight
+  // the image's last block is followed by its stored value (and suffix byte) when that is where it is expected
+  const uint64_t tail = (flags & TCRC_F_EXPECT_AFTER) ? (suffix_byte >= 0 ? 5u : 4u) : 0u;
+  const uint64_t bytes = (n_blocks - 1) * stride + block_len + tail;
+  if (int rc = upload(ctx, L, &L->data, h_base, bytes)) return rc;
+  // aux layout: [counts 3 x u64 | pad][expected n x u32][ok n]
+  const size_t off_expected = 32, off_ok = off_expected + n_blocks * 4;
+  if (int rc = scratch_reserve(ctx, &L->aux, off_ok + n_blocks + 64)) return rc;
+  uint8_t* aux = (uint8_t*)L->aux.p;
+  if (h_expected) HIP_TRY(hipMemcpyAsync(aux + off_expected, h_expected, n_blocks * 4, hipMemcpyHostToDevice, L->stream));
+  if (int rc = scratch_reserve(ctx, &L->out, n_blocks * 4)) return rc;
+  if (int rc = tcrc_dev_counts_reset(ctx, (uint64_t*)aux, L->stream)) return rc;
+  if (int rc = tcrc_dev_blocks_verify(ctx, L->data.p, n_blocks, block_len, stride, init, suffix_byte, nullptr, flags,
+                                      h_expected ? (const uint32_t*)(aux + off_expected) : nullptr,
+                                      (uint32_t*)L->out.p, aux + off_ok, (uint64_t*)aux, L->stream))
+    return rc;
+  if (h_out) HIP_TRY(hipMemcpyAsync(h_out, L->out.p, n_blocks * 4, hipMemcpyDeviceToHost, L->stream));
+  if (h_ok) HIP_TRY(hipMemcpyAsync(h_ok, aux + off_ok, n_blocks, hipMemcpyDeviceToHost, L->stream));
+  HIP_TRY(hipMemcpyAsync(h_counts, aux, 24, hipMemcpyDeviceToHost, L->stream));
+  guard.dismiss();
+  HIP_TRY(hipStreamSynchronize(L->stream));
+  return TCRC_OK;
+}
+
 int tcrc_host_batch_verify(tcrc_ctx* ctx, const void* h_base, uint64_t base_bytes, const tcrc_desc* h_desc, uint64_t n,
                            const uint8_t* h_suffix, uint32_t flags, const uint32_t* h_expected, uint32_t* h_out,
                            uint8_t* h_ok, uint64_t* h_counts) {

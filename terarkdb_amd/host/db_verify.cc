@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <memory>
+#include <thread>
 
 #include "wal_dump.h"
 
@@ -151,6 +152,47 @@ Status VerifyDbDirectory(tcrc_ctx* ctx, const std::string& dir, uint32_t shard_i
     }
   }
   return Status::OK();
+}
+
+Status VerifyDbDirectoryGroup(tcrc_group* group, const std::string& dir, DbVerifyReport* report,
+                              const SstVerifyOptions& options) {
+  const int members = tcrc_group_size(group);
+  if (members <= 0) return Status::InvalidArgument("empty group");
+  std::vector<DbVerifyReport> reps(members);
+  std::vector<Status> sts(members);
+  auto run = [&](int m) {
+    sts[m] = VerifyDbDirectory(tcrc_group_ctx(group, m), dir, static_cast<uint32_t>(m), static_cast<uint32_t>(members),
+                               &reps[m], options);
+  };
+  std::vector<std::thread> th;
+  for (int m = 1; m < members; ++m) th.emplace_back(run, m);
+  run(0);
+  for (auto& t : th) t.join();
+  int worst = -1;
+  for (int m = 0; m < members; ++m) {
+    const DbVerifyReport& r = reps[m];
+    report->table_files += r.table_files;
+    report->table_files_declined += r.table_files_declined;
+    report->table_blocks += r.table_blocks;
+    report->table_bytes_covered += r.table_bytes_covered;
+    report->log_files += r.log_files;
+    report->log_bytes += r.log_bytes;
+    report->log_records += r.log_records;
+    report->log_bad_records += r.log_bad_records;
+    report->log_notes.insert(report->log_notes.end(), r.log_notes.begin(), r.log_notes.end());
+    if (!sts[m].ok()) {
+      // file names are NNNNNN.sst: shorter or lexically smaller base name = smaller number
+      auto key = [](const std::string& path) {
+        const std::string base = path.substr(path.find_last_of('/') + 1);
+        return std::make_pair(base.size(), base);
+      };
+      if (worst < 0 || key(r.first_bad_file) < key(reps[worst].first_bad_file)) worst = m;
+    }
+  }
+  std::sort(report->log_notes.begin(), report->log_notes.end());
+  if (worst < 0) return Status::OK();
+  report->first_bad_file = reps[worst].first_bad_file;
+  return sts[worst];
 }
 
 }  // namespace terarkdb_amd

@@ -38,4 +38,11 @@ Status VerifyTableFiles(tcrc_ctx* ctx, const std::vector<std::string>& files, ui
 Status VerifyDbDirectory(tcrc_ctx* ctx, const std::string& dir, uint32_t shard_index, uint32_t shard_count,
                          DbVerifyReport* report, const SstVerifyOptions& options = SstVerifyOptions());
 
+// The same over a group of GPUs in one process (tcrc_group_init): shard m of the directory's files goes to member m,
+// every member on a host thread of its own, the way several processes with --shard=m/n would do it; the reports
+// add up.  If several shards fail, the status is that of the failing table with the smallest file number - the
+// first one DBImpl::VerifyChecksum's loop over the files (db/db_impl.cc:4667-4686) would have met among them.
+Status VerifyDbDirectoryGroup(tcrc_group* group, const std::string& dir, DbVerifyReport* report,
+                              const SstVerifyOptions& options = SstVerifyOptions());
+
 }  // namespace terarkdb_amd

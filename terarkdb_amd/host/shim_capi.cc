@@ -490,6 +490,21 @@ int tcrc_shim_verify_db(tcrc_ctx* ctx, const char* dir, uint32_t shard_index, ui
   return s.IsCorruption() ? 1 : -1;
 }
 
+int tcrc_shim_verify_db_group(tcrc_group* group, const char* dir, uint64_t* report_out, char* message, size_t message_cap,
+                              char* bad_file, size_t bad_file_cap) {
+  DbVerifyReport rep;
+  Status s = VerifyDbDirectoryGroup(group, dir, &rep);
+  if (report_out) {
+    const uint64_t v[8] = {rep.table_files, rep.table_files_declined, rep.table_blocks, rep.table_bytes_covered,
+                           rep.log_files,   rep.log_bytes,            rep.log_records,  rep.log_bad_records};
+    memcpy(report_out, v, sizeof(v));
+  }
+  if (message && message_cap) snprintf(message, message_cap, "%s", s.ToString().c_str());
+  if (bad_file && bad_file_cap) snprintf(bad_file, bad_file_cap, "%s", rep.first_bad_file.c_str());
+  if (s.ok()) return 0;
+  return s.IsCorruption() ? 1 : -1;
+}
+
 int tcrc_shim_file_checksum(tcrc_ctx* ctx, const char* path, uint64_t size_limit, size_t buffer_size,
                             uint32_t* checksum_out, uint64_t* size_out, char* message, size_t message_cap) {
   uint32_t crc = 0;

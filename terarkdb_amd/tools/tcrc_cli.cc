@@ -2,7 +2,7 @@
 //   tcrc crc32c [--block_size=N] [--bytes=N] [--device=D]      db_bench "crc32c" (tools/db_bench_tool.cc:3069-3088)
 //   tcrc verify FILE.sst...                                    sst_dump --command=verify (tools/sst_dump_tool.cc:656-665)
 //   tcrc dump_wal --walfile=F [--header] [--print_value]       ldb dump_wal (tools/ldb_cmd.cc:1967-2037)
-//   tcrc verify_db DIR [--shard=I/N]                           DBImpl::VerifyChecksum over the files of a
+//   tcrc verify_db DIR [--shard=I/N | --gpus=0,1,..]                           DBImpl::VerifyChecksum over the files of a
 //                                                              database directory (db/db_impl.cc:4657-4690), plus a
 //                                                              scan of its logs and MANIFEST files
 //   tcrc file_checksum FILE...                                 backup engine's CalculateChecksum
@@ -159,11 +159,19 @@ int CmdDumpWal(tcrc_ctx* ctx, int argc, char** argv) {
 int CmdVerifyDb(tcrc_ctx* ctx, int argc, char** argv) {
   std::string dir, v;
   uint32_t shard = 0, shards = 1;
+  std::vector<int> gpus;  // --gpus=0,1,...: the directory's files over a group of GPUs in this process
   for (int i = 0; i < argc; ++i) {
     if (Flag(argv[i], "--shard", &v)) {
       if (sscanf(v.c_str(), "%u/%u", &shard, &shards) != 2) {
         fprintf(stderr, "--shard=I/N\n");
         return 2;
+      }
+    } else if (Flag(argv[i], "--gpus", &v)) {
+      for (size_t at = 0; at < v.size();) {
+        gpus.push_back(atoi(v.c_str() + at));
+        const size_t comma = v.find(',', at);
+        if (comma == std::string::npos) break;
+        at = comma + 1;
       }
     } else if (argv[i][0] != '-') {
       dir = argv[i];
@@ -175,7 +183,18 @@ int CmdVerifyDb(tcrc_ctx* ctx, int argc, char** argv) {
   }
   DbVerifyReport rep;
   const double t0 = NowMicros();
-  Status s = VerifyDbDirectory(ctx, dir, shard, shards, &rep);
+  Status s;
+  if (!gpus.empty()) {
+    tcrc_group* group = nullptr;
+    if (tcrc_group_init(gpus.data(), (int)gpus.size(), &group) != TCRC_OK) {
+      fprintf(stderr, "%s\n", tcrc_last_error());
+      return 2;
+    }
+    s = VerifyDbDirectoryGroup(group, dir, &rep);
+    tcrc_group_shutdown(group);
+  } else {
+    s = VerifyDbDirectory(ctx, dir, shard, shards, &rep);
+  }
   const double t1 = NowMicros();
   printf("table files: %llu verified (%llu blocks, %llu bytes covered), %llu declined\n",
          (unsigned long long)rep.table_files, (unsigned long long)rep.table_blocks,
@@ -250,7 +269,7 @@ void Usage() {
           "  verify FILE.sst ...\n"
           "  dump_wal --walfile=FILE [--header] [--print_value]\n"
           "  verify_wal FILE.log ...\n"
-          "  verify_db DIR [--shard=I/N]\n"
+          "  verify_db DIR [--shard=I/N | --gpus=0,1,...]\n"
           "  file_checksum FILE ...\n");
 }
 

@@ -10,7 +10,7 @@ import oracle_lib as O
 import terarkdb_amd.capi as capi
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DECL = re.compile(r"^\s*(?:const\s+)?(?:int|void|uint32_t|uint64_t|size_t|char)\s*\*?\s*(tcrc_\w+)\s*\(", re.M)
+DECL = re.compile(r"^\s*(?:const\s+)?(?:int|void|uint32_t|uint64_t|size_t|char|tcrc_ctx)\s*\*?\s*(tcrc_\w+)\s*\(", re.M)
 
 
 def declared(header):
