@@ -284,6 +284,33 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    # The same exchange through the library's own entry point (ncclAllReduce sum + min on a communicator made
+    # from an id that rank 0 hands out): outside the timed region, a cross-check of the product's collective on
+    # whatever hardware this runs on.  A failure here is reported in the line, it does not void the measurement.
+    product_collective = None
+    if dist and not rehearsal:
+        try:
+            import ctypes as C
+            L = capi.lib
+            uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                raw = (C.c_uint8 * 128)()
+                capi.check(L.tcrc_rccl_get_unique_id(raw))
+                uid.copy_(torch.tensor(list(raw), dtype=torch.uint8))
+            dist.broadcast(uid, 0)
+            raw = (C.c_uint8 * 128)(*uid.cpu().tolist())
+            comm = C.c_void_p()
+            capi.check(L.tcrc_rccl_comm_init_rank(eng.ctx, world, raw, rank, C.byref(comm)))
+            mine = counts.clone()
+            capi.check(L.tcrc_rccl_allreduce_counts(eng.ctx, comm, C.c_void_p(mine.data_ptr()), lo, C.c_void_p(stream)))
+            torch.cuda.synchronize()
+            got = mine.cpu().tolist()
+            capi.check(L.tcrc_rccl_comm_destroy(comm))
+            want = [totals.mismatches, totals.first_bad, totals.checked]
+            product_collective = "ok" if got == want else f"differs: {got} != {want}"
+        except Exception as e:  # noqa: BLE001
+            product_collective = f"failed: {e}"
+
     mism, checked = totals.mismatches, totals.checked
     if mism != n_corrupt * args.steps or checked != TOTAL_BLOCKS * args.steps:
         raise SystemExit(f"verification miscounted: {mism} mismatches / {checked} checked")
@@ -333,7 +360,8 @@ def main():
                        "corpus_blocks": TOTAL_BLOCKS, "blocks_on_rank0": N_BLOCKS,
                        "sharding": "contiguous block range per GPU", "gib_folds_checked_on_rank0": gibs_checked,
                        "seeded_corruptions": n_corrupt,
-                       "collective": "one all-gather of {mismatches, checked, first_bad} (24 B per rank)" if dist else "none"},
+                       "collective": "one all-gather of {mismatches, checked, first_bad} (24 B per rank)" if dist else "none",
+                       **({"tcrc_rccl_allreduce_counts_cross_check": product_collective} if product_collective else {})},
             **({"rehearsal": f"{world} ranks sharing ONE GPU over gloo: a check of the sharded path, not a scaling result"}
                if rehearsal else {}),
             "pct_hbm_peak": round(100.0 * value / (HBM_PEAK_GBS * world), 2),
