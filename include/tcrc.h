@@ -144,6 +144,15 @@ int tcrc_dev_batch_verify(tcrc_ctx* ctx, const void* d_base, const tcrc_desc* d_
 int tcrc_dev_extend_long(tcrc_ctx* ctx, const void* d_base, const tcrc_desc* h_desc, uint64_t n, uint32_t segment_len,
                          uint32_t* d_out, void* stream);
 
+/* tcrc_dev_extend_long without the wait, for callers with many such calls in a row (whole-file checksums buffer
+ * after buffer, utilities/backupable/backupable_db.cc:1434-1449): the kernel is enqueued on `stream` and the
+ * call returns; d_out is complete once the stream has run, and only the last call of a row needs waiting for.
+ * At most 64 buffers per call (TCRC_ERR_TOO_LARGE beyond).  The partial results live in lines the context owns
+ * (allocated at the first long-buffer call): the enqueued calls of one context must run one after the other -
+ * one stream, or events between streams - and must not be mixed with tcrc_dev_extend_long calls still in flight. */
+int tcrc_dev_extend_long_enqueue(tcrc_ctx* ctx, const void* d_base, const tcrc_desc* h_desc, uint64_t n,
+                                 uint32_t segment_len, uint32_t* d_out, void* stream);
+
 /* tcrc_dev_extend_long for callers that cannot allocate (code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments and results,
  * with these limits: at most 64 buffers per call (TCRC_ERR_TOO_LARGE beyond), each up to 1 GiB.  The

@@ -52,6 +52,7 @@ SIGNATURES = {
     "tcrc_dev_wal_verify": (_i, [_vp, _vp, _u64, _u64, _vp, _vp, C.POINTER(_u64), _vp]),
     "tcrc_dev_extend_long": (_i, [_vp, _vp, _vp, _u64, _u32, _vp, _vp]),
     "tcrc_dev_extend_long_noalloc": (_i, [_vp, _vp, _vp, _u64, _u32, _vp, _vp]),
+    "tcrc_dev_extend_long_enqueue": (_i, [_vp, _vp, _vp, _u64, _u32, _vp, _vp]),
     "tcrc_dev_probe_read": (_i, [_vp, _vp, _u64, _vp, _u32, _vp]),
     "tcrc_dev_blocks_stamp": (_i, [_vp, _vp, _u64, _u32, _u64, _u32, _i, _vp, _u32, _vp, _vp]),
     "tcrc_dev_blocks_verify": (_i, [_vp, _vp, _u64, _u32, _u64, _u32, _i, _vp, _u32, _vp, _vp, _vp, _vp, _vp]),
@@ -265,14 +266,16 @@ class Engine:
                                     C.byref(n), self._stream(stream)))
         return n.value
 
-    def extend_long(self, base, offsets, lens, inits, out, segment_len=0, stream=None, noalloc=False):
+    def extend_long(self, base, offsets, lens, inits, out, segment_len=0, stream=None, noalloc=False, enqueue=False):
         """Host descriptor arrays, device data; out is a device int32/uint32 tensor of len(offsets).
-        noalloc=True takes the entry point that allocates nothing (at most 64 buffers; only enqueues)."""
+        noalloc=True takes the entry point that allocates nothing (at most 64 buffers; only enqueues);
+        enqueue=True the one that only enqueues (at most 64 buffers)."""
         n = len(offsets)
         arr = (Desc * max(n, 1))()
         for i in range(n):
             arr[i].offset, arr[i].len, arr[i].init = int(offsets[i]), int(lens[i]), int(inits[i])
-        fn = lib.tcrc_dev_extend_long_noalloc if noalloc else lib.tcrc_dev_extend_long
+        fn = (lib.tcrc_dev_extend_long_noalloc if noalloc else
+              lib.tcrc_dev_extend_long_enqueue if enqueue else lib.tcrc_dev_extend_long)
         check(fn(self.ctx, _dp(base), arr, n, segment_len, _dp(out), self._stream(stream)))
 
     def extend(self, init, data):

@@ -2328,12 +2328,10 @@ int tcrc_shutdown(tcrc_ctx* ctx) {
   }
   if (ctx->frame_stream) (void)hipStreamDestroy(ctx->frame_stream);
   for (auto& e : ctx->pin_free) (void)hipHostFree(e.first);
-  if (ctx->stage_ring) (void)hipHostFree(ctx->stage_ring);
+  stage_pool_destroy(ctx);
   if (ctx->long_pin) (void)hipHostFree(ctx->long_pin);
   if (ctx->long_flag) (void)hipHostFree(ctx->long_flag);
   if (ctx->wal_pin) (void)hipHostFree(ctx->wal_pin);
-  for (hipEvent_t ev : ctx->stage_done)
-    if (ev) (void)hipEventDestroy(ev);
   delete ctx;
   return TCRC_OK;
 }

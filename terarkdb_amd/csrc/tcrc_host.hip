@@ -9,6 +9,8 @@
 #include <string.h>
 
 #include <atomic>
+#include <condition_variable>
+#include <deque>
 #include <functional>
 #include <string>
 #include <thread>
@@ -107,69 +109,170 @@ bool is_pinned(const void* p, const void** dev = nullptr) {
   return true;
 }
 
-// Copies pageable host memory to the device through a ring of pinned slots: several host threads
-// fill slots while the copy engine drains them, which roughly doubles the rate of a plain
-// hipMemcpy from pageable memory (the runtime stages through one thread).
-int staged_upload(tcrc_ctx* ctx, tcrc_lane* L, void* d_dst, const void* h_src, size_t bytes) {
-  std::lock_guard<std::mutex> ring_lock(ctx->stage_mu);
-  constexpr int K = tcrc_ctx::kStageSlots;
-  constexpr size_t S = tcrc_ctx::kStageSlotBytes;
-  if (!ctx->stage_ring) {
-    HIP_TRY(hipHostMalloc((void**)&ctx->stage_ring, K * S, hipHostMallocDefault));
-    for (int i = 0; i < K; ++i) HIP_TRY(hipEventCreateWithFlags(&ctx->stage_done[i], hipEventDisableTiming));
-  }
-  const size_t n = (bytes + S - 1) / S;
-  std::vector<std::atomic<int>> filled(n), issued(n);
-  for (size_t i = 0; i < n; ++i) {
-    filled[i].store(0, std::memory_order_relaxed);
-    issued[i].store(0, std::memory_order_relaxed);
-  }
-  std::atomic<size_t> next{0};
-  std::atomic<int> failed{0};
-  const int device = ctx->device;
-  auto worker = [&]() {
-    (void)hipSetDevice(device);
-    for (;;) {
-      const size_t i = next.fetch_add(1);
-      if (i >= n || failed.load()) return;
-      if (i >= (size_t)K) {  // the slot still holds chunk i-K until its copy has been issued and has finished
-        while (!issued[i - K].load(std::memory_order_acquire))
-          if (failed.load()) return; else std::this_thread::yield();
-        if (hipEventSynchronize(ctx->stage_done[i % K]) != hipSuccess) {
-          failed.store(1);
-          return;
-        }
-      } else if (ctx->stage_recorded[i]) {
-        // the slot may still be the source of a copy that an EARLIER upload queued (a host call uploads its
-        // image and then its descriptors: the first upload returns with its last copies still in flight)
-        if (hipEventSynchronize(ctx->stage_done[i]) != hipSuccess) {
-          failed.store(1);
-          return;
-        }
-      }
-      const size_t off = i * S, len = bytes - off < S ? bytes - off : S;
-      memcpy(ctx->stage_ring + (i % K) * S, (const char*)h_src + off, len);
-      filled[i].store(1, std::memory_order_release);
-    }
+// Copies pageable host memory to the device through pinned slots: host threads fill slots while the copy engine
+// drains them, which roughly doubles the rate of a plain hipMemcpy from pageable memory (the runtime stages
+// through one thread).  The slots and the threads that fill them belong to the context and are shared by its
+// lanes: an upload takes free slots as it goes (never more than kStageAhead at a time), hands their filling to
+// the pool, and issues each slot's copy on its own lane's stream as soon as the slot is full; a slot goes back to
+// the free list when its copy has been issued, with the event that says when the copy is over - whoever takes
+// it next waits for that.  Uploads of several threads so share the pool slot by slot instead of taking turns
+// at whole copies.
+}  // namespace
+
+struct tcrc_stage_pool {
+  static constexpr int kSlots = tcrc_ctx::kStageSlots;
+  static constexpr size_t kSlotBytes = tcrc_ctx::kStageSlotBytes;
+  static constexpr int kWorkers = 8;
+  struct Task {
+    char* dst;
+    const char* src;
+    size_t len;
+    std::atomic<int>* filled;
   };
-  const int nthreads = (int)(n < 6 ? n : 6);
-  std::vector<std::thread> pool;
-  for (int t = 0; t < nthreads; ++t) pool.emplace_back(worker);
-  hipError_t err = hipSuccess;
-  for (size_t i = 0; i < n && err == hipSuccess; ++i) {
-    while (!filled[i].load(std::memory_order_acquire))
-      if (failed.load()) break; else std::this_thread::yield();
-    if (failed.load()) break;
-    const size_t off = i * S, len = bytes - off < S ? bytes - off : S;
-    err = hipMemcpyAsync((char*)d_dst + off, ctx->stage_ring + (i % K) * S, len, hipMemcpyHostToDevice, L->stream);
-    if (err == hipSuccess) err = hipEventRecord(ctx->stage_done[i % K], L->stream);
-    if (err == hipSuccess) ctx->stage_recorded[i % K] = true;  // read by later uploads only
-    issued[i].store(1, std::memory_order_release);
+  int device = 0;
+  char* ring = nullptr;
+  hipEvent_t done[kSlots] = {};
+  bool recorded[kSlots] = {};  // done[i] has been recorded at least once (read by whoever holds slot i)
+  std::mutex mu;
+  std::condition_variable slot_free, task_ready;
+  std::vector<int> free_slots;
+  std::deque<Task> tasks;
+  std::vector<std::thread> workers;
+  bool stop = false;
+
+  void work() {
+    for (;;) {
+      Task t;
+      {
+        std::unique_lock<std::mutex> lock(mu);
+        task_ready.wait(lock, [&] { return stop || !tasks.empty(); });
+        if (tasks.empty()) return;  // stop
+        t = tasks.front();
+        tasks.pop_front();
+      }
+      memcpy(t.dst, t.src, t.len);
+      t.filled->store(1, std::memory_order_release);
+    }
   }
-  if (err != hipSuccess) failed.store(1);
-  for (auto& t : pool) t.join();
+  // a free slot; with wait == false, -1 when there is none right now
+  int take_slot(bool wait) {
+    std::unique_lock<std::mutex> lock(mu);
+    if (!wait && free_slots.empty()) return -1;
+    slot_free.wait(lock, [&] { return !free_slots.empty(); });
+    const int s = free_slots.back();
+    free_slots.pop_back();
+    return s;
+  }
+  void give_slot(int s) {
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      free_slots.push_back(s);
+    }
+    slot_free.notify_one();
+  }
+  void submit(const Task& t) {
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      tasks.push_back(t);
+    }
+    task_ready.notify_one();
+  }
+};
+
+namespace tcrc_internal {
+void stage_pool_destroy(tcrc_ctx* ctx) {
+  tcrc_stage_pool* p = ctx->stage_pool;
+  if (!p) return;
+  {
+    std::lock_guard<std::mutex> lock(p->mu);
+    p->stop = true;
+  }
+  p->task_ready.notify_all();
+  for (auto& t : p->workers) t.join();
+  for (hipEvent_t ev : p->done)
+    if (ev) (void)hipEventDestroy(ev);
+  if (p->ring) (void)hipHostFree(p->ring);
+  delete p;
+  ctx->stage_pool = nullptr;
+}
+}  // namespace tcrc_internal
+
+namespace {
+
+constexpr int kStageAhead = 6;  // slots one upload has in hand at most (being filled, or full and not yet issued)
+
+int stage_pool_get(tcrc_ctx* ctx, tcrc_stage_pool** out) {
+  std::lock_guard<std::mutex> lock(ctx->stage_mu);
+  if (!ctx->stage_pool) {
+    tcrc_stage_pool* p = new tcrc_stage_pool();
+    p->device = ctx->device;
+    hipError_t e = hipHostMalloc((void**)&p->ring, tcrc_stage_pool::kSlots * tcrc_stage_pool::kSlotBytes, hipHostMallocDefault);
+    for (int i = 0; i < tcrc_stage_pool::kSlots && e == hipSuccess; ++i)
+      e = hipEventCreateWithFlags(&p->done[i], hipEventDisableTiming);
+    if (e != hipSuccess) {
+      for (hipEvent_t ev : p->done)
+        if (ev) (void)hipEventDestroy(ev);
+      if (p->ring) (void)hipHostFree(p->ring);
+      delete p;
+      return fail(TCRC_ERR_HIP, std::string("staging slots: ") + hipGetErrorString(e));
+    }
+    for (int i = 0; i < tcrc_stage_pool::kSlots; ++i) p->free_slots.push_back(i);
+    for (int i = 0; i < tcrc_stage_pool::kWorkers; ++i) p->workers.emplace_back([p] { p->work(); });
+    ctx->stage_pool = p;
+  }
+  *out = ctx->stage_pool;
+  return TCRC_OK;
+}
+
+int staged_upload(tcrc_ctx* ctx, tcrc_lane* L, void* d_dst, const void* h_src, size_t bytes) {
+  tcrc_stage_pool* P = nullptr;
+  if (int rc = stage_pool_get(ctx, &P)) return rc;
+  constexpr size_t S = tcrc_stage_pool::kSlotBytes;
+  const size_t n = (bytes + S - 1) / S;
+  struct InHand {
+    int slot;
+    std::atomic<int> filled{0};
+  };
+  std::deque<InHand> hand;  // in chunk order (a deque never moves its elements: the workers hold pointers to `filled`)
+  hipError_t err = hipSuccess;
+  size_t next_fill = 0, next_issue = 0;
+  while (next_issue < n) {
+    // take slots and hand them to the pool while there is something left to fill and room in hand
+    while (next_fill < n && hand.size() < (size_t)kStageAhead && err == hipSuccess) {
+      // (an upload only waits for a slot when it has none in hand: with some in hand it goes on to issue those,
+      // which is what frees slots - uploads that all held a few and all waited for more would never finish)
+      const int slot = P->take_slot(hand.empty());
+      if (slot < 0) break;
+      // the slot may still be the source of a copy that an earlier upload (of any lane) queued
+      if (P->recorded[slot]) err = hipEventSynchronize(P->done[slot]);
+      hand.emplace_back();
+      hand.back().slot = slot;
+      if (err != hipSuccess) {
+        hand.back().filled.store(1);  // nothing will fill it
+        break;
+      }
+      const size_t off = next_fill * S, len = bytes - off < S ? bytes - off : S;
+      P->submit(tcrc_stage_pool::Task{P->ring + (size_t)slot * S, (const char*)h_src + off, len, &hand.back().filled});
+      ++next_fill;
+    }
+    if (err != hipSuccess) break;
+    // the oldest slot in hand: wait for it to be full, issue its copy, give it back
+    InHand& h = hand.front();
+    while (!h.filled.load(std::memory_order_acquire)) std::this_thread::yield();
+    const size_t off = next_issue * S, len = bytes - off < S ? bytes - off : S;
+    err = hipMemcpyAsync((char*)d_dst + off, P->ring + (size_t)h.slot * S, len, hipMemcpyHostToDevice, L->stream);
+    if (err == hipSuccess) err = hipEventRecord(P->done[h.slot], L->stream);
+    if (err == hipSuccess) P->recorded[h.slot] = true;
+    P->give_slot(h.slot);
+    hand.pop_front();
+    ++next_issue;
+  }
+  // on an error: whatever is still in hand is waited for (a worker may be writing into it) and given back
+  for (InHand& h : hand) {
+    while (!h.filled.load(std::memory_order_acquire)) std::this_thread::yield();
+    P->give_slot(h.slot);
+  }
   if (err != hipSuccess) return fail(TCRC_ERR_HIP, std::string("staged upload: ") + hipGetErrorString(err));
-  if (failed.load()) return fail(TCRC_ERR_HIP, "staged upload: a staging thread failed");
   return TCRC_OK;
 }
 

@@ -241,6 +241,8 @@ int run_wal_frame(tcrc_ctx* ctx, WalFrameParams p, bool phase_dst, void* stream)
 const uint32_t* wal_piece_powers();
 // Per-device set-up of the long-buffer path at tcrc_init (the context's GPU is current): the power tables.
 int long_device_setup(tcrc_ctx* ctx);
+// Stops the staging threads of the context and frees its pinned slots (tcrc_shutdown).
+void stage_pool_destroy(tcrc_ctx* ctx);
 // Gives the context's slice of the static accumulator lines back (tcrc_shutdown).
 void long_device_release(tcrc_ctx* ctx);
 
@@ -319,6 +321,7 @@ struct tcrc_lane {
   uint32_t done_seq = 0;             // value the next such launch writes (never 0)
 };
 
+struct tcrc_stage_pool;
 struct tcrc_ctx {
   int device = -1;
   int cus = 0;
@@ -369,15 +372,12 @@ struct tcrc_ctx {
   // Layout constants of a lane's zero-copy block (tcrc_lane::zc)
   static constexpr size_t kZcData = (size_t)64 << 10;     // bounce area for short pageable inputs
   static constexpr size_t kZcMaxItems = 4096;
-  // Staging ring for uploads from pageable memory (tcrc_host.hip), shared by the lanes: stage_mu is held while
-  // an upload fills and issues its slots; the slots' events say when a slot's copy (on whichever lane's stream)
-  // has finished
+  // Staging for uploads from pageable memory (tcrc_host.hip): pinned slots and the threads that fill them, shared
+  // by the lanes, made at the first large upload (stage_mu guards the making)
   std::mutex stage_mu;
-  static constexpr int kStageSlots = 12;
+  static constexpr int kStageSlots = 24;
   static constexpr size_t kStageSlotBytes = (size_t)4 << 20;
-  char* stage_ring = nullptr;  // kStageSlots * kStageSlotBytes of pinned memory
-  hipEvent_t stage_done[kStageSlots] = {};
-  bool stage_recorded[kStageSlots] = {};  // stage_done[i] has been recorded at least once
+  struct tcrc_stage_pool* stage_pool = nullptr;
   // running totals (tcrc_get_stats)
   std::atomic<uint64_t> st_batch_launches{0}, st_batch_buffers{0}, st_host_calls{0}, st_host_bytes_in{0},
       st_host_nanos{0}, st_log_images{0}, st_log_bytes{0}, st_long_calls{0}, st_long_bytes{0};

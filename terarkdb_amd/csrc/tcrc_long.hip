@@ -296,6 +296,37 @@ extern "C" int tcrc_dev_extend_long(tcrc_ctx* ctx, const void* d_base, const tcr
   return TCRC_OK;
 }
 
+// tcrc_dev_extend_long without the wait: the kernel is enqueued on `stream` and the call returns; d_out is complete
+// once the stream has run.  For callers with many such calls in a row (a backup engine checksumming file after
+// file through its buffers): a call that waits pays the launch, the kernel's first microseconds - the table
+// fill, one memory latency - and the wait for its last arrival, each time; enqueued back to back, one kernel's
+// beginning runs under the end of the one before, and only the last call is waited for.
+// At most kLongInline buffers (their descriptors travel in the kernel arguments; nothing is staged).  The
+// accumulator lines belong to the context: the enqueued calls of one context must run one after the other - one
+// stream, or events between streams.
+extern "C" int tcrc_dev_extend_long_enqueue(tcrc_ctx* ctx, const void* d_base, const tcrc_desc* h_desc, uint64_t n,
+                                            uint32_t segment_len, uint32_t* d_out, void* stream) {
+  if (!ctx) return fail(TCRC_ERR_INVALID, "null context");
+  if (n == 0) return TCRC_OK;
+  if (!d_base || !h_desc || !d_out) return fail(TCRC_ERR_INVALID, "null argument");
+  if (n > (uint64_t)kLongInline)
+    return fail(TCRC_ERR_TOO_LARGE, "tcrc_dev_extend_long_enqueue takes at most 64 buffers per call");
+  TCRC_DEVICE_SCOPE(ctx);
+  LongArgs la;
+  uint64_t nseg = 0, total = 0;
+  if (int rc = plan_inline(ctx, h_desc, (uint32_t)n, segment_len, &la, &nseg, &total)) return rc;
+  std::lock_guard<std::mutex> lock(ctx->long_mu);  // (for the duration of the enqueue: the lines' allocation)
+  ctx->st_long_calls.fetch_add(1, std::memory_order_relaxed);
+  ctx->st_long_bytes.fetch_add(total, std::memory_order_relaxed);
+  if (int rc = acc_reserve(ctx, (hipStream_t)stream)) return rc;
+  la.acc = (uint32_t*)ctx->long_acc.p;
+  BatchParams p{};
+  p.base = (const uint8_t*)d_base;
+  p.out = d_out;
+  p.n = nseg;
+  return run_segments(ctx, p, la, stream);
+}
+
 // The same for callers that must not allocate (a HIP graph being captured, a serving loop, a harness that
 // forbids it): at most kLongInline buffers, accumulator lines in the library's static device memory, one
 // small kernel that clears the lines and the checksum kernel enqueued on `stream`, nothing else - no allocation,

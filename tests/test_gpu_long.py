@@ -84,3 +84,35 @@ def test_batch_of_64_and_chaining(eng):
     assert crc == O.value(host, "hw")
     # the same file in one call
     assert int(run(eng, dev, [0], [host.size], [0])[0]) == crc
+
+
+def test_enqueued_calls_in_a_row(eng):
+    """tcrc_dev_extend_long_enqueue: a row of calls on one stream, different buffers and outputs, one wait at the
+    end; every call's values equal the waiting entry point's and the oracle's.  Chaining through init across the
+    row is what a whole-file checksum does buffer after buffer."""
+    import gpu_util as G
+    import terarkdb_amd.capi as capi
+    host = O.splitmix(24 << 20, 4711)
+    dev = G.to_dev(host)
+    rng = np.random.default_rng(3)
+    calls = []
+    for k in range(12):
+        n = int(rng.integers(1, 65))
+        lens = [int(rng.integers(0, 300000)) for _ in range(n)]
+        offs = [int(rng.integers(0, host.size - ln)) for ln in lens]
+        inits = [int(rng.integers(0, 2**32)) for _ in range(n)]
+        out = torch.full((n,), 0x55555555, dtype=torch.int32, device="cuda")
+        calls.append((offs, lens, inits, out))
+    for offs, lens, inits, out in calls:
+        eng.extend_long(dev, offs, lens, inits, out, enqueue=True)  # only enqueues
+    torch.cuda.synchronize()
+    for offs, lens, inits, out in calls:
+        want = O.batch_extend(host, np.array(offs, np.uint64), np.array(lens, np.uint32), np.array(inits, np.uint32))
+        assert (out.cpu().numpy().view(np.uint32) == want).all()
+    # a waiting call right behind enqueued ones sees the lines clean
+    offs, lens, inits, out = calls[0]
+    ref = torch.zeros_like(out)
+    eng.extend_long(dev, offs, lens, inits, ref)
+    assert torch.equal(ref, out)
+    with pytest.raises(capi.TcrcError, match="at most 64 buffers"):
+        eng.extend_long(dev, [0] * 65, [10] * 65, [0] * 65, torch.zeros(65, dtype=torch.int32, device="cuda"), enqueue=True)

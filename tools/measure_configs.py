@@ -155,11 +155,12 @@ def run_spans(eng):
 
 
 def run_long(eng, only_single):
-    S = O.splitmix(64 * 4 * 1024 * 1024, 301)
+    S = O.splitmix((256 << 20) if only_single else (1 << 30), 301)  # the asymptote: one buffer of 1 GiB
     dS = torch.from_numpy(S).cuda()
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     L = capi.lib
-    for n, sizes, single in ((1, (256 << 10, 1 << 20, 4 << 20), True), (64, (4 << 20,), False), (1, (256 << 20,), False)):
+    for n, sizes, single in ((1, (256 << 10, 1 << 20, 4 << 20), True), (64, (4 << 20,), False), (1, (256 << 20,), False),
+                             (1, (1 << 30,), False)):
         if single != only_single:
             continue
         for sz in sizes:
@@ -183,6 +184,16 @@ def run_long(eng, only_single):
             line(name, f"{n} buffer(s) of {sz} bytes per tcrc_dev_extend_long call, host call to completion "
                        "(one kernel launch and one stream synchronisation)", "k_crc_batch<8> (segments)", n * sz, sec,
                  note="wall clock per call: includes the launch and the wait for completion")
+            # the same calls enqueued back to back (tcrc_dev_extend_long_enqueue), one wait at the end
+            enq = lambda: capi.check(L.tcrc_dev_extend_long_enqueue(eng.ctx, C.c_void_p(dS.data_ptr()), d, n, 0,  # noqa: E731
+                                                                     C.c_void_p(out.data_ptr()), stream))
+            out.zero_()
+            enq()
+            torch.cuda.synchronize()
+            assert (out.cpu().numpy().view(np.uint32) == want).all()
+            line(name + "_enqueued", f"{n} buffer(s) of {sz} bytes per tcrc_dev_extend_long_enqueue call, calls "
+                                     "enqueued back to back, HIP events around the row of calls",
+                 "k_crc_batch<8> (segments)", n * sz, sustained(enq))
 
 
 def main():
