@@ -1462,6 +1462,13 @@ __global__ __launch_bounds__(kThreads) void k_wal_split(WalScanParams p) {
   bool p_done = false;
   // Returns 0 when every span it took found room, 1 when the ring or the slots had no room for some, 2 when the
   // list was empty.
+  // Experiment: rounds the placer may be ahead of the tickets handed out (0: as many as the ring holds)
+  const uint32_t lead_max = (p.tune >> 16) & 0xffu;
+  auto lead_cap = [&](uint32_t open) -> uint32_t {
+    if (lead_max == 0u) return open;
+    const uint32_t lim = uni(lds_load(&ctl[0])) + lead_max;
+    return open < lim ? open : lim;
+  };
   auto place_step = [&]() -> int {
     // One look at the ring before anything else: with less than a round's worth of room the step could place
     // next to nothing, and all it would do is work out that it is blocked (a scan that waits for its checksum
@@ -1472,6 +1479,7 @@ __global__ __launch_bounds__(kThreads) void k_wal_split(WalScanParams p) {
       const unsigned long long m = __ballot(mine);
       p_open += m == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~m);
       if (p_open > (p_count >> 3) + kWalStepRounds) p_open = (p_count >> 3) + kWalStepRounds;
+      p_open = lead_cap(p_open);
       if (p_open * 8u - p_count < 8u && (p_count & 7u) == 0u) return 1;
     }
     const uint32_t listed = uni(lds_acquire(&ctl[4]));
@@ -1547,6 +1555,7 @@ __global__ __launch_bounds__(kThreads) void k_wal_split(WalScanParams p) {
       const unsigned long long m = __ballot(mine);
       p_open += m == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~m);
       if (p_open > (p_count >> 3) + kWalStepRounds) p_open = (p_count >> 3) + kWalStepRounds;
+      p_open = lead_cap(p_open);
     }
     const uint32_t room = p_open * 8u - p_count;
     // spans take room in list order; those that no longer fit stay in the list.  A span of several pieces also
