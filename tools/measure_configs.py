@@ -10,8 +10,12 @@ the CPU oracle (checker only: nothing here times it).
 Names: log_2k (the 1M-record db_bench log, 2.05 GB), log_mixed, log_mixed_recyclable (256 MiB, sizes
 Random(301).Skewed(17)), blocks4k_var, blocks8k_var (1 GiB of table-builder-sized blocks packed with their
 trailers: verify against, and stamp into, the image), spans_2k (the batch kernel alone on 2046-byte spans at
-every alignment), long_64x4m (64 buffers of 4 MiB in one call, and one buffer of 256 MiB), long_single (one
-buffer of 256 KiB / 1 MiB / 4 MiB per call, host call to completion).  Under rocprofv3 run one name at a time.
+every alignment), long_64x4m (64 buffers of 4 MiB in one call), long_256m and long_1g (one buffer of 256 MiB, of
+1 GiB), long_single (one buffer of 256 KiB / 1 MiB / 4 MiB per call, host call to completion; each long shape
+also with the calls enqueued back to back), log_small_128 / log_small_512 / log_small_1k
+(64 MB logs of records of 100..160, 400..600 and 900..1100 bytes: the header walk is what they wait for), frame_2040
+(device framing of 131 108 records of 2040 bytes into a 256 MiB log image: payload read once, image written once).
+Under rocprofv3 run one name at a time.
 """
 import argparse
 import ctypes as C
@@ -70,6 +74,19 @@ def log_image(kind):
         size = t.written_bytes()
         covered = int(OL.oracle_wal_writer_crc_bytes(t.writer))
         lognum = 7
+    elif kind.startswith("small:"):
+        lo, hi = (int(x) for x in kind.split(":")[1:])
+        rng = np.random.default_rng(1)
+        filler = O.splitmix(1 << 16, 9).tobytes()
+        t = O.OracleLog(recycle=False, log_number=9)
+        acc = 0
+        while acc < 64 << 20:
+            n = int(rng.integers(lo, hi + 1))
+            t.write(filler[:n])
+            acc += n + 7
+        size = t.written_bytes()
+        covered = None
+        lognum = 9
     else:
         recycle = kind == "mixed_recyclable"
         t = O.OracleLog(recycle=recycle, log_number=123)
@@ -101,8 +118,8 @@ def run_log(eng, name, kind, workload):
     torch.cuda.synchronize()
     assert (blocks.cpu().numpy().view(np.uint32) == want).all() and n == int(want[:, 0].sum())
     sec = sustained(lambda: eng.wal_verify(dev, img.size, lognum, blocks, counts, want_records=False))
-    line(name, workload, "k_wal_fused", covered, sec, image_bytes=int(img.size), physical_records=int(n),
-         per_block_results_equal_cpu_reader_rules=True)
+    line(name, workload, "k_wal_split", covered, sec, image_bytes=int(img.size), physical_records=int(n),
+         records_in_the_fullest_block=int(want[:, 0].max()), per_block_results_equal_cpu_reader_rules=True)
 
 
 def run_blocks_var(eng, name, target):
@@ -154,15 +171,42 @@ def run_spans(eng):
          "k_crc_batch<8>", n * L, sustained(fn))
 
 
-def run_long(eng, only_single):
-    S = O.splitmix((256 << 20) if only_single else (1 << 30), 301)  # the asymptote: one buffer of 1 GiB
+def run_frame(eng):
+    n, ln = 131108, 2040  # the first 256 MiB of the db_bench log
+    lens = np.full(n, ln, np.uint32)
+    offs = np.arange(n, dtype=np.uint64) * ln
+    payload = n * ln
+    src = O.splitmix((payload + 64 + 7) // 8 * 8, 301)
+    dsrc = torch.from_numpy(src).cuda()
+    plan = eng.wal_plan(offs.tolist(), lens.tolist(), 7, False)
+    dst = torch.zeros(plan.image_bytes + 64, dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    fn = lambda: eng.wal_frame_enqueue(plan, dsrc, dst, stream=stream)  # noqa: E731
+    fn()
+    torch.cuda.synchronize()
+    w = O.OracleLog(recycle=False, log_number=7)
+    for o in offs.tolist():
+        w.write(src[int(o):int(o) + ln].tobytes())
+    assert dst.cpu().numpy()[:plan.image_bytes].tobytes() == w.contents()
+    w.close()
+    sec = sustained(fn)
+    line("frame_2040", f"frame {n} records of {ln} bytes resident in HBM into a log image ({plan.physical_records} physical "
+                       f"records, {plan.image_bytes} bytes): one kernel reads the payload once, writes the image once and "
+                       "checksums what passes through its registers; the plan is made once, outside the launches",
+         "k_wal_frame", payload + plan.image_bytes, sec, payload_bytes=payload, image_bytes=int(plan.image_bytes),
+         payload_GBps=round(payload / sec / 1e9, 1), image_equals_cpu_writer=True)
+    plan.close()
+
+
+def run_long(eng, which):
+    """which: "single" (256 KiB, 1 MiB, 4 MiB, one buffer per call), "64x4m", "256m", "1g" (the asymptote)"""
+    shapes = {"single": (1, (256 << 10, 1 << 20, 4 << 20)), "64x4m": (64, (4 << 20,)), "256m": (1, (256 << 20,)),
+              "1g": (1, (1 << 30,))}[which]
+    S = O.splitmix((1 << 30) if which == "1g" else (256 << 20), 301)
     dS = torch.from_numpy(S).cuda()
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     L = capi.lib
-    for n, sizes, single in ((1, (256 << 10, 1 << 20, 4 << 20), True), (64, (4 << 20,), False), (1, (256 << 20,), False),
-                             (1, (1 << 30,), False)):
-        if single != only_single:
-            continue
+    for n, sizes in (shapes,):
         for sz in sizes:
             d = (capi.Desc * n)()
             for i in range(n):
@@ -215,16 +259,20 @@ def main():
                                            "edge-case records, legacy headers")
     if want("log_mixed_recyclable"):
         run_log(eng, "log_mixed_recyclable", "mixed_recyclable", "the same with recyclable headers")
+    for nm, lo, hi in (("log_small_128", 100, 160), ("log_small_512", 400, 600), ("log_small_1k", 900, 1100)):
+        if want(nm):
+            run_log(eng, nm, f"small:{lo}:{hi}", f"verify a 64 MB log of records of {lo}..{hi} bytes, legacy headers")
+    if want("frame_2040"):
+        run_frame(eng)
     if want("blocks4k_var"):
         run_blocks_var(eng, "blocks4k_var", 4096)
     if want("blocks8k_var"):
         run_blocks_var(eng, "blocks8k_var", 8192)
     if want("spans_2k"):
         run_spans(eng)
-    if want("long_64x4m"):
-        run_long(eng, only_single=False)
-    if want("long_single"):
-        run_long(eng, only_single=True)
+    for nm in ("64x4m", "256m", "1g", "single"):
+        if want("long_" + nm):
+            run_long(eng, nm)
     eng.close()
 
 

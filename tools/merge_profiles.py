@@ -30,6 +30,9 @@ cp("hbm_traffic.json", f"{rnd}_bench_pmc_hbm_traffic.json")
 cp("hbm_traffic.json", "hbm_traffic.json")
 cp("bench_8gib_shard.json", f"{rnd}_bench_8gib_shard.json")
 cp("latency.txt", f"{rnd}_latency.txt")
+cp("bench_sq.json", f"{rnd}_bench_sq.json")
+cp("frame.txt", f"{rnd}_frame.txt")
+cp("log_small.txt", f"{rnd}_log_small.txt")
 
 
 def trace_avg(path, needle):
@@ -48,13 +51,14 @@ out = []
 for l in open(os.path.join(src, "configs.jsonl")):
     d = json.loads(l)
     name = d["config"]
-    key = {"long_64x4096k": "long_64x4m"}.get(name, name)
-    if name.startswith("long_1x"):
+    base = name[:-len("_enqueued")] if name.endswith("_enqueued") else name
+    key = {"long_64x4096k": "long_64x4m", "long_1x262144k": "long_256m", "long_1x1048576k": "long_1g"}.get(base, base)
+    if key.startswith("long_1x"):
         key = "long_single"
-    shared_run = name.startswith("long_1x")  # several shapes in one profiled command: no per-shape kernel average
-    if name == "long_1x262144k":
-        key = "long_64x4m"  # measured in the same command as the 64 x 4 MiB shape
-    needle = "k_wal_fused" if name.startswith("log_") else "k_crc_batch"
+    # several shapes in one profiled command, or the waiting and the enqueued calls of one shape (the same kernel on
+    # the same buffers; the trace's average is over both): no per-line kernel average for the enqueued line
+    shared_run = key == "long_single" or name.endswith("_enqueued")
+    needle = d["roofline"]["kernel"].split("<")[0].split(" ")[0]
     if key:
         cp(f"{key}_kernel_stats.csv", f"{rnd}_{key}_kernel_stats.csv")
         cp(f"{key}_hbm_traffic.json", f"{rnd}_{key}_hbm_traffic.json")
@@ -66,6 +70,9 @@ for l in open(os.path.join(src, "configs.jsonl")):
         if os.path.exists(t) and not shared_run:
             d["roofline"]["traffic"] = json.load(open(t)).get("bytes_per_launch")
         d["evidence"] = [f"profiles/{rnd}_{key}_kernel_stats.csv", f"profiles/{rnd}_{key}_hbm_traffic.json"]
+        if os.path.exists(os.path.join(src, f"{key}_sq.json")):
+            cp(f"{key}_sq.json", f"{rnd}_{key}_sq.json")
+            d["evidence"].append(f"profiles/{rnd}_{key}_sq.json")
     out.append(d)
 with open(os.path.join(dst, f"{rnd}_configs.json"), "w") as f:
     for d in out:
