@@ -5,8 +5,8 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 CFG=${CFG:-log_2k}; NEEDLE=${NEEDLE:-k_wal_}
 O=gpurun_out/tcc_$CFG
 rm -rf $O && mkdir -p $O
-timeout -s KILL 120 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_BUBBLE_sum TCC_EA0_RDREQ_DRAM_sum -d $O/a -o a -- python3 tools/measure_configs.py --only $CFG --launches 5 --settle 0.2 > $O/a.log 2>&1 || exit 1
-timeout -s KILL 120 rocprofv3 --pmc TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_READ_sum -d $O/b -o b -- python3 tools/measure_configs.py --only $CFG --launches 5 --settle 0.2 > $O/b.log 2>&1 || exit 1
+timeout -k 10 120 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_BUBBLE_sum TCC_EA0_RDREQ_DRAM_sum -d $O/a -o a -- python3 tools/measure_configs.py --only $CFG --launches 5 --settle 0.2 > $O/a.log 2>&1 || exit 1
+timeout -k 10 120 rocprofv3 --pmc TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_READ_sum -d $O/b -o b -- python3 tools/measure_configs.py --only $CFG --launches 5 --settle 0.2 > $O/b.log 2>&1 || exit 1
 python3 - <<PY
 import sqlite3
 for db in ("$O/a/a_results.db", "$O/b/b_results.db"):
