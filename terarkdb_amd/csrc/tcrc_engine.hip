@@ -1314,7 +1314,7 @@ __global__ __launch_bounds__(kThreads) void k_wal_split(WalScanParams p) {
   stamp(1, 0);
 
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (said to be the same in every lane: the branches on it are scalar then)
   const int j = lane & (G - 1);
   const int grp = lane / G;
   const uint32_t LB = (uint32_t)(lane & 31) * 4u | 0x10000u;
@@ -1344,82 +1344,85 @@ __global__ __launch_bounds__(kThreads) void k_wal_split(WalScanParams p) {
   uint32_t w_blk = 0, w_pos = 0, w_k = 0;
   uint32_t w_len = 0;          // bytes of the lane's block that are in the image (32768 but for the image's last block)
   auto w_ptr = [&]() -> const uint8_t* { return p.img + (uint64_t)w_blk * kLogBlockBytes; };  // the block's first byte
-  bool w_active = false, w_done = false;
-  // bit 0: w_hdr holds header bytes 4..11 under the cursor, fetched with one 8-byte load (>= 12 bytes were left);
-  // bit 1: w_hdr is not the header under the lane's cursor (its record found no room in the list, or the walker
-  // has been away on a round: the header registers do not live across one)
-  // (one word on purpose: two flags set in the two arms of a branch end up in memory, behind a selected address)
-  uint32_t w_flags = 0;
+  // 0: the lane has no block; 1: it has one, and the header under its cursor has to be fetched and decoded the
+  // general way (fewer than twelve bytes are left in the block); 3: it has one, and w_hdr holds header bytes 4..11
+  // under the cursor, fetched with one 8-byte load
+  uint32_t w_state = 0;
+  bool w_done = false;
   uint32_t l_wr = 0;                     // spans listed so far (the same in every lane)
   uint32_t l_room = kSplitListEntries;   // places in the list known to be free
   const uint32_t ln32 = (uint32_t)p.log_number;
   const bool ln_fits = (p.log_number >> 32) == 0;  // a recyclable header holds 32 bits: a larger log number never matches
-  // One step: every active lane looks at the header under its cursor (fetched by the step before) and lists the
-  // record's checksummed span.  Returns true if the list had no room for some record.
-  // The common case - at least twelve bytes left in the block, a header that passes every check of
-  // db/log_reader.cc:317-384 - is decoded without a branch, in 32-bit arithmetic relative to the block; whatever
-  // else a lane meets (the last bytes of a block, a header that ends the block's walk) takes the general
-  // wal_fetch / wal_decode, which the whole wave then steps through once.
+  // One step: every lane with a block looks at the header under its cursor (fetched by the step before) and lists
+  // the record's checksummed span.  Returns true if the list had no room for some record.
+  // The step is one wave's chain of dependent instructions and nothing else bounds a log of small records, so it
+  // is written for few instructions and few branches: the common case - at least twelve bytes left in the block, a
+  // header that passes every check of db/log_reader.cc:317-384 - is decoded in 32-bit arithmetic relative to the
+  // block with the conditions combined bitwise (with && the compiler branches around every operand); whatever else
+  // a lane meets (the last bytes of a block, a header that ends the block's walk) takes the general wal_fetch /
+  // wal_decode, which the whole wave then steps through once.
   auto walk_step = [&](WalHeader& w_hdr) -> bool {
     WalHeader hdr = w_hdr;
-    const unsigned long long idle = __ballot(!w_active);
-    if (idle && w_next < b_hi) {
-      const uint32_t nv = w_next + lanes_below(idle);
-      const uint32_t nb = block_of(nv);
-      if (!w_active && nv < b_hi && nb < p.nblocks) {
-        w_active = true;
-        w_blk = nb;
-        w_pos = 0;
-        w_k = 0;
-        const uint64_t bbase = (uint64_t)nb * kLogBlockBytes;
-        w_len = (uint32_t)(block_end(nb) - bbase);
-        p.blocks[nb].first_bad = 0xffffffffu;  // lowered by whoever finds a bad checksum in the block
-        w_flags = w_len >= 12u ? 1u : 0u;
-        if (w_flags) {
-          uint2 w;
-          __builtin_memcpy(&w, w_ptr() + 4, 8);
-          hdr.lo = w.x;
-          hdr.hi = w.y;
+    if (w_next < b_hi) {
+      const unsigned long long idle = __ballot(w_state == 0u);
+      if (idle) {
+        const uint32_t nv = w_next + lanes_below(idle);
+        const uint32_t nb = block_of(nv);
+        if (w_state == 0u && nv < b_hi && nb < p.nblocks) {
+          w_blk = nb;
+          w_pos = 0;
+          w_k = 0;
+          const uint64_t bbase = (uint64_t)nb * kLogBlockBytes;
+          w_len = (uint32_t)(block_end(nb) - bbase);
+          p.blocks[nb].first_bad = 0xffffffffu;  // lowered by whoever finds a bad checksum in the block
+          w_state = w_len >= 12u ? 3u : 1u;
+          if (w_state == 3u) {
+            uint2 w;
+            __builtin_memcpy(&w, w_ptr() + 4, 8);
+            hdr.lo = w.x;
+            hdr.hi = w.y;
+          }
         }
+        const uint32_t handed = w_next + (uint32_t)__popcll(idle);
+        w_next = handed < b_hi ? handed : b_hi;
       }
-      const uint32_t handed = w_next + (uint32_t)__popcll(idle);
-      w_next = handed < b_hi ? handed : b_hi;
     }
-    if (!__any(w_active)) {
-      if (lane == 0) lds_store(&ctl[4], l_wr | 0x80000000u);  // the count is final
-      w_done = true;
-      return false;
-    }
-    const uint32_t rem = w_len - w_pos;
-    const uint32_t type = (hdr.lo >> 16) & 0xffu;
     uint32_t len = hdr.lo & 0xffffu;
+    const uint32_t type = (hdr.lo >> 16) & 0xffu;
     const bool recyc = type - 5u < 4u;
     uint32_t hs = recyc ? kLogRecyclableHeader : kLogHeader;
     const uint32_t lognum = __builtin_amdgcn_alignbyte(hdr.hi, hdr.lo, 3);  // header bytes 7..10
-    bool ok = w_active && (w_flags & 1u) != 0u && hs + len <= rem && (hdr.lo & 0xffffffu) != 0u &&
-              (!recyc || (lognum == ln32 && ln_fits));
-    if (__any(w_active && !ok)) {
-      if (w_active && !ok) {
+    uint32_t npos = w_pos + hs + len;
+    bool ok = (w_state == 3u) & (npos <= w_len) & ((hdr.lo & 0xffffffu) != 0u) & (!recyc | ((lognum == ln32) & ln_fits));
+    if (__any((w_state != 0u) & !ok)) {
+      if ((w_state != 0u) & !ok) {
         const uint64_t base = (uint64_t)w_blk * kLogBlockBytes;
         const uint64_t end = base + w_len;
         const bool last = p.tail && end == p.size;
         uint32_t code = 0;
         WalHeader h = hdr;
-        if (!(w_flags & 1u)) h = wal_fetch(p.img, base + w_pos, end);
+        if (w_state != 3u) h = wal_fetch(p.img, base + w_pos, end);
         ok = wal_decode(h, base + w_pos, end, last, p.log_number, &hs, &len, &code);
+        npos = w_pos + hs + len;
         if (!ok) {  // the block's walk ends here
           tcrc_wal_block* b = p.blocks + w_blk;
           b->n_records = w_k;
           b->end_offset = w_pos;
           b->end_code = code;
           atomicAdd(&ctl[6], w_k);  // the workgroup's candidate records
-          w_active = false;
+          w_state = 0u;
         }
       }
     }
+    // from here on a lane has a block exactly if its record is good
+    const unsigned long long m_ok = __ballot(ok);
+    if (m_ok == 0ull && w_next >= b_hi) {
+      if (lane == 0) lds_store(&ctl[4], l_wr | 0x80000000u);  // the count is final
+      w_done = true;
+      return false;
+    }
     // the next header is asked for before anything else is done with this record
-    const uint32_t npos = w_pos + hs + len;
-    const bool fastn = ok && w_len - npos >= 12u;
+    const bool fastn = ok & (w_len - npos >= 12u);
     WalHeader nxt = {0u, 0u};
     if (fastn) {
       uint2 w;
@@ -1427,16 +1430,15 @@ __global__ __launch_bounds__(kThreads) void k_wal_split(WalScanParams p) {
       nxt.lo = w.x;
       nxt.hi = w.y;
     }
-    const unsigned long long m_ok = __ballot(ok);
     const uint32_t cnt = (uint32_t)__popcll(m_ok);
     if (cnt > l_room) l_room = kSplitListEntries - (l_wr - uni(lds_acquire(&ctl[5])));
     const uint32_t below = lanes_below(m_ok);
-    if (ok && below < l_room) {
+    if (ok & (below < l_room)) {
       // the CRC covers the type byte, the log number if any, and the payload: [pos + 6, pos + hs + len)
       rlist[(l_wr + below) % kSplitListEntries] = make_uint2(w_blk, (w_pos + 6u) | ((len + hs - 6u) << 15));
       w_pos = npos;
       ++w_k;
-      w_flags = fastn ? 1u : 0u;
+      w_state = fastn ? 3u : 1u;
     }
     // Unconditionally, so that the load is waited for where the next step decodes it and not here: a lane whose
     // record found no room ends the walk loop (the step returns true) and fetches its header again when the
@@ -1666,106 +1668,9 @@ __global__ __launch_bounds__(kThreads) void k_wal_split(WalScanParams p) {
     return uni(got);
   };
 
-  uint32_t spins = 0;
-  for (;;) {
-    if (lds_load(&ctl[2])) break;  // some wave of the workgroup gave up waiting
-    uint32_t t = 0;
-    if (wave == 0 && !w_done) {
-      if (!(p.tune & 4u)) __builtin_amdgcn_s_setprio(3);  // the walk is the critical path of a workgroup with little to do
-      // the walker's cursors and counters come out of LDS (see w_save), and the header under every cursor is fetched
-      {
-        const uint4 sv = w_save[lane];
-        w_blk = sv.x & 0x7fffffffu;
-        w_active = (sv.x >> 31) != 0u;
-        w_pos = sv.y;
-        w_k = sv.z;
-        w_len = sv.w;
-        w_next = uni(u_save[0]);
-        l_wr = uni(u_save[1]);
-        l_room = uni(u_save[2]);
-      }
-      WalHeader w_hdr = {0u, 0u};
-      w_flags = (w_active && w_len - w_pos >= 12u) ? 1u : 0u;
-      if (w_flags) {
-        uint2 w;
-        __builtin_memcpy(&w, w_ptr() + w_pos + 4u, 8);
-        w_hdr.lo = w.x;
-        w_hdr.hi = w.y;
-      }
-      bool blocked = false;
-      uint32_t steps = 0;
-      do {
-        blocked = walk_step(w_hdr);
-      } while (!blocked && !w_done && ((++steps & 31u) != 0u || !lds_load(&ctl[2])));  // the give-up flag: a look every 32 steps
-      __builtin_amdgcn_s_setprio(0);
-      if (!blocked) {
-        if (w_done) stamp(2, 0);
-        continue;
-      }
-      w_save[lane] = make_uint4(w_blk | (w_active ? 0x80000000u : 0u), w_pos, w_k, w_len);
-      if (lane == 0) {
-        u_save[0] = w_next;
-        u_save[1] = l_wr;
-        u_save[2] = l_room;
-      }
-      t = try_claim();
-      if (t == 0xffffffffu) {
-        __builtin_amdgcn_s_sleep(4);
-        if (++spins > kWalSpinLimit) lds_store(&ctl[2], 1u);
-        continue;
-      }
-    } else if (wave == 1 && !p_done) {
-      if (!(p.tune & 4u)) __builtin_amdgcn_s_setprio(2);
-      p_rd = uni(u_save[4]);
-      p_count = uni(u_save[5]);
-      p_open = uni(u_save[6]);
-      p_spans = uni(u_save[7]);
-      int st = 0;
-      do {
-        st = place_step();
-      } while (st == 0 && !p_done && !lds_load(&ctl[2]));
-      __builtin_amdgcn_s_setprio(0);
-      if (p_done) {
-        stamp(3, 64);
-        continue;
-      }
-      if (st == 0) continue;
-      if (lane == 0) {
-        u_save[4] = p_rd;
-        u_save[5] = p_count;
-        u_save[6] = p_open;
-        u_save[7] = p_spans;
-      }
-      t = try_claim();
-      if (t == 0xffffffffu) {
-        if (st == 2) __builtin_amdgcn_s_sleep(1);  // an empty list is looked at again soon
-        else __builtin_amdgcn_s_sleep(4);
-        if (++spins > kWalSpinLimit) lds_store(&ctl[2], 1u);
-        continue;
-      }
-    } else {
-      if (lane == 0) t = atomicAdd(&ctl[0], 1u);
-      t = uni(t);
-      bool over = false;
-      for (;;) {
-        const uint32_t sq = uni(lds_acquire(&seq[t % RR]));
-        if (sq == t + 1u) break;
-        const uint32_t total = uni(lds_load(&ctl[1]));
-        if (t >= total || lds_load(&ctl[2])) {
-          over = true;
-          break;
-        }
-        __builtin_amdgcn_s_sleep(8);
-        if (++spins > kWalSpinLimit) {
-          lds_store(&ctl[2], 1u);
-          over = true;
-          break;
-        }
-      }
-      if (over) break;
-    }
-    spins = 0;
-    // round t: the entries are copied out, and the round is handed back to the placer
+  // One round: the entries are copied out, the round is handed back to the placer, and the eight pieces are
+  // checksummed.
+  auto do_round = [&](uint32_t t) {
     const uint2 e = ring[(t % RR) * 8u + grp];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every lane has its entry before the round is given away
     if (lane == 0) lds_release(&seq[t % RR], t + RR);
@@ -1818,6 +1723,125 @@ __global__ __launch_bounds__(kThreads) void k_wal_split(WalScanParams p) {
           if (want != ((crc >> 15) | (crc << 17)) + kMaskDelta) mismatch(sblk, sstart);
         }
       }
+    }
+  };
+  // Takes the next ticket and waits for its round; false when there is none any more.
+  uint32_t spins = 0;
+  auto next_round = [&](uint32_t& t) -> bool {
+    if (lane == 0) t = atomicAdd(&ctl[0], 1u);
+    t = uni(t);
+    bool over = false;
+    for (;;) {
+      const uint32_t sq = uni(lds_acquire(&seq[t % RR]));
+      if (sq == t + 1u) break;
+      const uint32_t total = uni(lds_load(&ctl[1]));
+      if (t >= total || lds_load(&ctl[2])) {
+        over = true;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > kWalSpinLimit) {
+        lds_store(&ctl[2], 1u);
+        over = true;
+        break;
+      }
+    }
+    if (over) return false;
+    return true;
+  };
+  if (wave >= 2) {
+    // The fourteen waves that only checksum run a loop of their own: in one loop with the walker and the placer,
+    // whatever those keep in registers across their steps (constants the compiler hoists out of the step) is live
+    // across the row loops too, and a few registers more there change how the table lookups are scheduled (four
+    // in flight instead of sixteen, 3 % on a scan that waits for its checksums).
+    for (;;) {
+      if (lds_load(&ctl[2])) break;  // some wave of the workgroup gave up waiting
+      uint32_t t = 0;
+      if (!next_round(t)) break;
+      spins = 0;
+      do_round(t);
+    }
+  } else {
+    for (;;) {
+      if (lds_load(&ctl[2])) break;  // some wave of the workgroup gave up waiting
+      uint32_t t = 0;
+      if (wave == 0 && !w_done) {
+        if (!(p.tune & 4u)) __builtin_amdgcn_s_setprio(3);  // the walk is the critical path of a workgroup with little to do
+        // the walker's cursors and counters come out of LDS (see w_save), and the header under every cursor is fetched
+        {
+          const uint4 sv = w_save[lane];
+          w_blk = sv.x & 0x7fffffffu;
+          w_pos = sv.y;
+          w_k = sv.z;
+          w_len = sv.w;
+          w_state = (sv.x >> 31) == 0u ? 0u : (w_len - w_pos >= 12u ? 3u : 1u);
+          w_next = uni(u_save[0]);
+          l_wr = uni(u_save[1]);
+          l_room = uni(u_save[2]);
+        }
+        WalHeader w_hdr = {0u, 0u};
+        if (w_state == 3u) {
+          uint2 w;
+          __builtin_memcpy(&w, w_ptr() + w_pos + 4u, 8);
+          w_hdr.lo = w.x;
+          w_hdr.hi = w.y;
+        }
+        bool blocked = false;
+        uint32_t steps = 0;
+        do {
+          blocked = walk_step(w_hdr);
+        } while (!blocked && !w_done && ((++steps & 31u) != 0u || !uni(lds_load(&ctl[2]))));  // the give-up flag: a look every 32 steps
+        __builtin_amdgcn_s_setprio(0);
+        if (!blocked) {
+          if (w_done) stamp(2, 0);
+          continue;
+        }
+        w_save[lane] = make_uint4(w_blk | (w_state != 0u ? 0x80000000u : 0u), w_pos, w_k, w_len);
+        if (lane == 0) {
+          u_save[0] = w_next;
+          u_save[1] = l_wr;
+          u_save[2] = l_room;
+        }
+        t = try_claim();
+        if (t == 0xffffffffu) {
+          __builtin_amdgcn_s_sleep(4);
+          if (++spins > kWalSpinLimit) lds_store(&ctl[2], 1u);
+          continue;
+        }
+      } else if (wave == 1 && !p_done) {
+        if (!(p.tune & 4u)) __builtin_amdgcn_s_setprio(2);
+        p_rd = uni(u_save[4]);
+        p_count = uni(u_save[5]);
+        p_open = uni(u_save[6]);
+        p_spans = uni(u_save[7]);
+        int st = 0;
+        do {
+          st = place_step();
+        } while (st == 0 && !p_done && !uni(lds_load(&ctl[2])));
+        __builtin_amdgcn_s_setprio(0);
+        if (p_done) {
+          stamp(3, 64);
+          continue;
+        }
+        if (st == 0) continue;
+        if (lane == 0) {
+          u_save[4] = p_rd;
+          u_save[5] = p_count;
+          u_save[6] = p_open;
+          u_save[7] = p_spans;
+        }
+        t = try_claim();
+        if (t == 0xffffffffu) {
+          if (st == 2) __builtin_amdgcn_s_sleep(1);  // an empty list is looked at again soon
+          else __builtin_amdgcn_s_sleep(4);
+          if (++spins > kWalSpinLimit) lds_store(&ctl[2], 1u);
+          continue;
+        }
+      } else {
+        if (!next_round(t)) break;
+      }
+      spins = 0;
+      do_round(t);
     }
   }
   stamp(31, 0);
