@@ -1251,17 +1251,19 @@ __global__ __launch_bounds__(kThreads) void k_wal_fused(WalScanParams p) {
 // ---- log scan, walker and placer apart ------------------------------------------------------------------
 // The same scan with the header walk cut down to what is sequential.  In k_wal_fused one dependent step per record
 // decodes the header, works out the record's pieces, finds room in the ring and slots for them and writes them;
-// here wave 0 only chases headers (fetch, the structural checks of db/log_reader.cc:317-384, advance) and appends
-// one 8-byte (block, start, length) entry per checksummed span to a list in LDS, in one ballot.  Wave 1 takes up to
-// 64 entries of that list per step - parallel over records, no header chain in its way - and does what is left:
+// here wave 0 only chases headers (fetch, the structural checks of db/log_reader.cc:317-384, advance) and every
+// lane appends one 8-byte (block, start, length) entry per checksummed span to a short queue of its own in LDS -
+// no ballot, no shared counter, and a lane whose queue is full waits by itself.  Wave 1 takes up to 64 entries of
+// those queues per step, dealt over the queues that have any - parallel over records, no header chain in its way -
+// and does what is left:
 // piece counts, places in the ring from ballots, slots for spans of several pieces, the ring writes.  Both go on
 // to checksum rounds like the other fourteen waves when they have nothing else to do.
-constexpr uint32_t kSplitRingRounds = 136;   // rounds of 8 entries in the ring (8.5 KiB)
-constexpr uint32_t kSplitListEntries = 256;  // spans the walker may be ahead of the placer (2 KiB)
+constexpr uint32_t kSplitRingRounds = 32;    // rounds of 8 entries in the ring (2 KiB)
+constexpr uint32_t kSplitListEntries = 1024;  // spans the walker may be ahead of the placer (8 KiB), shared out among its lanes' queues
 constexpr uint32_t kSplitHelpMin = 12;       // walker and placer take a round themselves only with this many waiting
 // Small records: how far in front of the walker's cursor the placer asks for the image's 64-byte sectors, up to
 // which span length a record counts as small, and the number of waiting rounds from which on it stops asking
-constexpr uint32_t kSplitAhead = 1024, kSplitAheadSpan = 640, kSplitAheadBacklog = 32;
+constexpr uint32_t kSplitAhead = 1024, kSplitAheadSpan = 640, kSplitAheadBacklog = 16;
 // classes of pieces that share rounds: longer than kSplitLong bytes, longer than kSplitShort, and the rest
 constexpr uint32_t kSplitLong = 1024, kSplitShort = 256;
 
@@ -1278,9 +1280,16 @@ __global__ __launch_bounds__(kThreads) void k_wal_split(WalScanParams p) {
   __shared__ uint2 rlist[kSplitListEntries];
   __shared__ WalSlot slots[kWalSlots];
   // [0] next ticket, [1] rounds in all once everything is placed (till then ~0), [2] set when a wait ran out,
-  // [3] rounds that are out, [4] spans the walker has listed (bit 31: and the walk is over), [5] spans the placer has taken,
-  // [6] candidate records of the blocks walked so far
+  // [3] rounds that are out, [4] bit 31: the walk is over, [6] candidate records of the blocks walked so far
   __shared__ uint32_t ctl[8];
+  // The walker's lanes' queues, in rlist: the workgroup's first Q = 2^qs lanes walk (Q: the number of its blocks
+  // rounded up to a power of two, at most 64), queue i has 1024 / Q places, and entry number e of queue i lies at
+  // ((e mod places) << qs) + i.  An entry: .x = block, .y = start | length << 15.
+  // qctr[i]: .x entries the walker's lane i has put into its queue (written behind the entry: the LDS performs a
+  // wave's operations in order), .y entries the placer has taken from it; both mod 65536.
+  // qmap: the queues that have entries, listed by the placer for its step.
+  __shared__ uint2 qctr[64];
+  __shared__ uint8_t qmap[64];
   __shared__ uint32_t pow_piece[64];  // [q * 4 + l]: x^(8 * kWalPiece * q) * x^(8 l)
   __shared__ uint32_t ahead_sink[64];  // where the sectors asked for ahead of the walker land (never read)
   // The walker's cursors and counters (wave 0) and the placer's counters (wave 1) while those waves are away on a
@@ -1309,7 +1318,8 @@ __global__ __launch_bounds__(kThreads) void k_wal_split(WalScanParams p) {
   if (tid < 64) pow_piece[tid] = p.pow_piece[tid];
   if (tid < 8) ctl[tid] = tid == 1 ? 0xffffffffu : 0u;
   if (tid < 64) w_save[tid] = make_uint4(0u, 0u, 0u, 0u);
-  if (tid < 8) u_save[tid] = tid == 2 ? kSplitListEntries : 0u;
+  if (tid < 8) u_save[tid] = 0u;
+  if (tid < 64) qctr[tid] = make_uint2(0u, 0u);
   __syncthreads();
   stamp(1, 0);
 
@@ -1332,6 +1342,14 @@ __global__ __launch_bounds__(kThreads) void k_wal_split(WalScanParams p) {
     return e < p.size ? e : p.size;
   };
   auto uni = [](uint32_t v) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+  // the lanes in which a condition holds, straight from the comparison (__ballot and __any take an int: the
+  // condition is first made a number and then compared with zero again, and the walker's step counts instructions)
+  auto lanes_where = [](bool c) -> unsigned long long { return __builtin_amdgcn_ballot_w64(c); };
+  // the queues' geometry
+  const uint32_t lanes_used = b_hi < 64u ? b_hi : 64u;
+  const uint32_t qs = lanes_used <= 1u ? 0u : 32u - (uint32_t)__builtin_clz(lanes_used - 1u);  // log2 of the queues
+  const uint32_t cap_shift = 10u - qs;                                                         // log2 of a queue's places
+  const uint32_t cap = 1u << cap_shift;
   auto lds_acquire = [](const uint32_t* q) -> uint32_t {
     return __hip_atomic_load(q, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
   };
@@ -1349,22 +1367,25 @@ __global__ __launch_bounds__(kThreads) void k_wal_split(WalScanParams p) {
   // under the cursor, fetched with one 8-byte load
   uint32_t w_state = 0;
   bool w_done = false;
-  uint32_t l_wr = 0;                     // spans listed so far (the same in every lane)
-  uint32_t l_room = kSplitListEntries;   // places in the list known to be free
+  uint32_t w_seq = 0;  // entries the lane has put into its queue so far (mod 65536 where it is kept)
   const uint32_t ln32 = (uint32_t)p.log_number;
   const bool ln_fits = (p.log_number >> 32) == 0;  // a recyclable header holds 32 bits: a larger log number never matches
-  // One step: every lane with a block looks at the header under its cursor (fetched by the step before) and lists
-  // the record's checksummed span.  Returns true if the list had no room for some record.
+  // One step: every lane with a block looks at the header under its cursor (fetched by the step before) and puts
+  // the record's checksummed span into its queue.  Returns true if some lane's queue had no room.
   // The step is one wave's chain of dependent instructions and nothing else bounds a log of small records, so it
   // is written for few instructions and few branches: the common case - at least twelve bytes left in the block, a
   // header that passes every check of db/log_reader.cc:317-384 - is decoded in 32-bit arithmetic relative to the
   // block with the conditions combined bitwise (with && the compiler branches around every operand); whatever else
   // a lane meets (the last bytes of a block, a header that ends the block's walk) takes the general wal_fetch /
   // wal_decode, which the whole wave then steps through once.
-  auto walk_step = [&](WalHeader& w_hdr) -> bool {
-    WalHeader hdr = w_hdr;
+  // walk_run: steps until the walk is over (returns 2), some lane's queue is full (1) or, looked at every 32 steps,
+  // some wave of the workgroup has given up waiting (0).  hdr: header bytes 4..11 under every cursor in state 3.
+  auto walk_run = [&](WalHeader hdr) -> uint32_t {
+   uint32_t steps = 0;
+   for (;;) {
+    const uint32_t tk = lds_load(&qctr[lane].y);  // asked for now, looked at when the record is known to be good
     if (w_next < b_hi) {
-      const unsigned long long idle = __ballot(w_state == 0u);
+      const unsigned long long idle = lanes_where(w_state == 0u);
       if (idle) {
         const uint32_t nv = w_next + lanes_below(idle);
         const uint32_t nb = block_of(nv);
@@ -1394,8 +1415,9 @@ __global__ __launch_bounds__(kThreads) void k_wal_split(WalScanParams p) {
     const uint32_t lognum = __builtin_amdgcn_alignbyte(hdr.hi, hdr.lo, 3);  // header bytes 7..10
     uint32_t npos = w_pos + hs + len;
     bool ok = (w_state == 3u) & (npos <= w_len) & ((hdr.lo & 0xffffffu) != 0u) & (!recyc | ((lognum == ln32) & ln_fits));
-    if (__any((w_state != 0u) & !ok)) {
-      if ((w_state != 0u) & !ok) {
+    const bool odd = (w_state != 0u) & !ok;
+    if (lanes_where(odd) != 0ull) {
+      if (odd) {
         const uint64_t base = (uint64_t)w_blk * kLogBlockBytes;
         const uint64_t end = base + w_len;
         const bool last = p.tail && end == p.size;
@@ -1415,55 +1437,56 @@ __global__ __launch_bounds__(kThreads) void k_wal_split(WalScanParams p) {
       }
     }
     // from here on a lane has a block exactly if its record is good
-    const unsigned long long m_ok = __ballot(ok);
+    const unsigned long long m_ok = lanes_where(ok);
     if (m_ok == 0ull && w_next >= b_hi) {
-      if (lane == 0) lds_store(&ctl[4], l_wr | 0x80000000u);  // the count is final
+      if (lane == 0) lds_store(&ctl[4], 0x80000000u);  // behind the last entry: the LDS performs a wave's operations in order
       w_done = true;
-      return false;
+      return 2u;
     }
-    // the next header is asked for before anything else is done with this record
-    const bool fastn = ok & (w_len - npos >= 12u);
+    // The next header is asked for before anything else is done with this record - or, by a lane whose queue is
+    // full, the header under its cursor once more: such a lane stays where it is for a step while the others go
+    // on, and its load, like theirs, is waited for where the next step decodes it.
+    const bool room = ((w_seq - tk) & 0xffffu) < cap;
+    const bool go = ok & room;
+    const uint32_t at = room ? npos : w_pos;
+    const bool fastn = ok & (w_len - at >= 12u);
     WalHeader nxt = {0u, 0u};
     if (fastn) {
       uint2 w;
-      __builtin_memcpy(&w, w_ptr() + npos + 4u, 8);
+      __builtin_memcpy(&w, w_ptr() + at + 4u, 8);
       nxt.lo = w.x;
       nxt.hi = w.y;
     }
-    const uint32_t cnt = (uint32_t)__popcll(m_ok);
-    if (cnt > l_room) l_room = kSplitListEntries - (l_wr - uni(lds_acquire(&ctl[5])));
-    const uint32_t below = lanes_below(m_ok);
-    if (ok & (below < l_room)) {
+    if (go) {
       // the CRC covers the type byte, the log number if any, and the payload: [pos + 6, pos + hs + len)
-      rlist[(l_wr + below) % kSplitListEntries] = make_uint2(w_blk, (w_pos + 6u) | ((len + hs - 6u) << 15));
+      rlist[((w_seq & (cap - 1u)) << qs) + (uint32_t)lane] = make_uint2(w_blk, (w_pos + 6u) | ((len + hs - 6u) << 15));
+      ++w_seq;
+      asm volatile("" ::: "memory");  // the count goes out behind the entry
+      lds_store(&qctr[lane].x, w_seq);
       w_pos = npos;
       ++w_k;
-      w_state = fastn ? 3u : 1u;
     }
-    // Unconditionally, so that the load is waited for where the next step decodes it and not here: a lane whose
-    // record found no room ends the walk loop (the step returns true) and fetches its header again when the
-    // walker comes back.
-    w_hdr = nxt;
-    const uint32_t nfit = cnt < l_room ? cnt : l_room;
-    if (nfit) {
-      l_wr += nfit;
-      l_room -= nfit;
-      // (no release fence: the LDS performs one wave's operations in the order they were issued, so whoever
-      // sees the count sees the entries; the fence would make every step wait for its own write to come back)
-      asm volatile("" ::: "memory");
-      if (lane == 0) lds_store(&ctl[4], l_wr);
+    if (ok) w_state = fastn ? 3u : 1u;
+    hdr = nxt;
+    if (lanes_where(ok & !room) != 0ull) {
+      // Some queue is full.  If rounds are waiting for checksum waves, the scan is not waiting for the walk: the
+      // walker goes and takes one (so it did whenever its list was full).  If not - a log of small records, the
+      // other waves idle - it walks on with the lanes that can, unless none can.
+      if (lanes_where(go) == 0ull) return 1u;
+      const uint32_t out = uni(lds_load(&ctl[3])), tickets = uni(lds_load(&ctl[0]));
+      if ((int32_t)(out - tickets) >= (int32_t)kSplitHelpMin) return 1u;
     }
-    return cnt > nfit;
+    if ((++steps & 31u) == 0u && uni(lds_load(&ctl[2])) != 0u) return 0u;
+   }
   };
 
   // ---- the placer (wave 1): up to 64 listed spans per step
-  uint32_t p_rd = 0;     // spans taken from the list so far (the same in every lane)
   uint32_t p_count = 0;  // entries written to the ring so far
   uint32_t p_open = 0;   // rounds [0, p_open) are known to be the placer's to write or already written
   uint32_t p_spans = 0;  // spans of several pieces so far: span n uses slot n mod kWalSlots
   bool p_done = false;
   // Returns 0 when every span it took found room, 1 when the ring or the slots had no room for some, 2 when the
-  // list was empty.
+  // queues were empty.  Lane l looks at queue l mod Q, at the entry l / Q behind the ones taken so far.
   // Experiment: rounds the placer may be ahead of the tickets handed out (0: as many as the ring holds)
   const uint32_t lead_max = (p.tune >> 16) & 0xffu;
   auto lead_cap = [&](uint32_t open) -> uint32_t {
@@ -1484,10 +1507,31 @@ __global__ __launch_bounds__(kThreads) void k_wal_split(WalScanParams p) {
       p_open = lead_cap(p_open);
       if (p_open * 8u - p_count < 8u && (p_count & 7u) == 0u) return 1;
     }
-    const uint32_t listed = uni(lds_acquire(&ctl[4]));
-    const uint32_t over = listed >> 31;
-    const uint32_t avail = (listed & 0x7fffffffu) - p_rd;
-    if (avail == 0u) {
+    const uint32_t over = uni(lds_acquire(&ctl[4])) >> 31;  // looked at before the queues: if set, every entry is in
+    // The queues that have entries are listed, and the step's 64 lanes dealt over them: lane l takes queue
+    // number l mod A of the list, at depth l / A behind the entries taken so far (A queues in the list) - one
+    // busy block's queue alone is emptied 64 entries at a step, 64 busy ones one entry each.
+    uint32_t avail_q = 0;
+    if ((uint32_t)lane < (1u << qs)) {
+      const uint2 c = qctr[lane];
+      avail_q = (c.x - c.y) & 0xffffu;
+    }
+    const unsigned long long m_q = lanes_where(avail_q != 0u);
+    bool has = false;
+    uint32_t qi = 0, eseq = 0;
+    uint2 e = make_uint2(0u, 0u);
+    if (m_q != 0ull) {
+      const uint32_t A = (uint32_t)__popcll(m_q);
+      if (avail_q != 0u) qmap[lanes_below(m_q)] = (uint8_t)lane;
+      const uint32_t qd = (uint32_t)((float)lane / (float)A);  // exact: both below 2^24, and a quotient that is no integer is 1/64 off one
+      qi = qmap[(uint32_t)lane - qd * A];  // (read behind the writes: one wave's LDS operations are performed in order)
+      const uint2 c = qctr[qi];
+      has = qd < ((c.x - c.y) & 0xffffu);
+      eseq = c.y + qd;
+      if (has) e = rlist[((eseq & (cap - 1u)) << qs) + qi];
+    }
+    const unsigned long long m_has = lanes_where(has);
+    if (m_has == 0ull) {
       if (!over) return 2;
       // Everything is placed: the last round is padded with empty entries and goes out, and the number of rounds
       // is made known.  (The round is the placer's: p_open covers a round it has written entries into.)
@@ -1503,10 +1547,6 @@ __global__ __launch_bounds__(kThreads) void k_wal_split(WalScanParams p) {
       p_done = true;
       return 0;
     }
-    const uint32_t n = avail < 64u ? avail : 64u;
-    const bool has = (uint32_t)lane < n;
-    uint2 e = make_uint2(0u, 0u);
-    if (has) e = rlist[(p_rd + lane) % kSplitListEntries];
     const uint32_t blk = e.x, start = e.y & 0x7fffu, span = e.y >> 15;
     const uint32_t c = has ? (span + kWalPiece - 1u) / kWalPiece : 0u;  // 1..16 pieces
     const bool multi = c > 1u;
@@ -1541,8 +1581,8 @@ __global__ __launch_bounds__(kThreads) void k_wal_split(WalScanParams p) {
     const unsigned long long m_multi = __ballot(multi);
     uint32_t step_entries = 0, below_e = 0;
     if (m_multi == 0ull) {
-      step_entries = n;
-      below_e = (uint32_t)lane;
+      step_entries = (uint32_t)__popcll(m_has);
+      below_e = lanes_below(m_has);
     } else {
 #pragma unroll
       for (int b = 0; b < 5; ++b) {
@@ -1571,7 +1611,7 @@ __global__ __launch_bounds__(kThreads) void k_wal_split(WalScanParams p) {
       before_busy = m_busy == 0ull || lane < __builtin_ctzll(m_busy);
     }
     const bool fits = has && upto_e <= room && before_busy;
-    const unsigned long long m_fit = __ballot(fits);  // a run of lanes from lane 0 on
+    const unsigned long long m_fit = __ballot(fits);  // the first so many of the lanes that have an entry
     // Where the step's entries go.  A round takes as long as its longest entry, so entries that are alike should
     // share rounds: the step's entries are laid down by class - first all pieces longer than kSplitLong bytes
     // (every piece but a span's first is kWalPiece long), then the first pieces above kSplitShort bytes, then the
@@ -1618,21 +1658,22 @@ __global__ __launch_bounds__(kThreads) void k_wal_split(WalScanParams p) {
         lds_store(&slots[slot].remaining, c + 1u);
       }
     }
-    const uint32_t nfit = (uint32_t)__popcll(m_fit);
-    if (nfit) {
-      const uint32_t new_count = p_count + uni((uint32_t)__shfl((int)upto_e, (int)nfit - 1));
+    if (m_fit) {
+      const uint32_t new_count = p_count + uni((uint32_t)__shfl((int)upto_e, 63 - __builtin_clzll(m_fit)));
       p_spans += (uint32_t)__popcll(m_fit & m_multi);
       // rounds that are complete now go out: lane i publishes round (old count / 8) + i
       const uint32_t r0 = p_count >> 3, r1 = new_count >> 3;
       if ((uint32_t)lane < r1 - r0) lds_release(&seq[(r0 + lane) % RR], r0 + lane + 1u);
       p_count = new_count;
-      p_rd += nfit;
-      if (lane == 0) {
-        lds_store(&ctl[3], r1);
-        lds_release(&ctl[5], p_rd);  // the list's places are free again: behind the reads above
-      }
+      // The queues' places are free again (behind the reads above).  The entries taken from one queue are its
+      // first so many (its lanes are l, l + A, ... in depth order, and the lanes that fit are the first so many
+      // that have an entry): the lane that took the last of them says how many that makes.
+      const uint32_t nl = (uint32_t)lane + (uint32_t)__popcll(m_q);
+      const bool more = nl < 64u && ((m_fit >> (nl & 63u)) & 1ull) != 0ull;
+      if (fits && !more) lds_store(&qctr[qi].y, eseq + 1u);
+      if (lane == 0) lds_store(&ctl[3], r1);
     }
-    return nfit == n ? 0 : 1;
+    return m_fit == m_has ? 0 : 1;
   };
 
   // A checksum that does not match: counted, and the record's index inside its block - found by walking the
@@ -1773,11 +1814,10 @@ __global__ __launch_bounds__(kThreads) void k_wal_split(WalScanParams p) {
           w_blk = sv.x & 0x7fffffffu;
           w_pos = sv.y;
           w_k = sv.z;
-          w_len = sv.w;
+          w_len = sv.w & 0xffffu;
+          w_seq = sv.w >> 16;
           w_state = (sv.x >> 31) == 0u ? 0u : (w_len - w_pos >= 12u ? 3u : 1u);
           w_next = uni(u_save[0]);
-          l_wr = uni(u_save[1]);
-          l_room = uni(u_save[2]);
         }
         WalHeader w_hdr = {0u, 0u};
         if (w_state == 3u) {
@@ -1786,22 +1826,14 @@ __global__ __launch_bounds__(kThreads) void k_wal_split(WalScanParams p) {
           w_hdr.lo = w.x;
           w_hdr.hi = w.y;
         }
-        bool blocked = false;
-        uint32_t steps = 0;
-        do {
-          blocked = walk_step(w_hdr);
-        } while (!blocked && !w_done && ((++steps & 31u) != 0u || !uni(lds_load(&ctl[2]))));  // the give-up flag: a look every 32 steps
+        const uint32_t how = walk_run(w_hdr);
         __builtin_amdgcn_s_setprio(0);
-        if (!blocked) {
-          if (w_done) stamp(2, 0);
+        if (how != 1u) {
+          if (how == 2u) stamp(2, 0);
           continue;
         }
-        w_save[lane] = make_uint4(w_blk | (w_state != 0u ? 0x80000000u : 0u), w_pos, w_k, w_len);
-        if (lane == 0) {
-          u_save[0] = w_next;
-          u_save[1] = l_wr;
-          u_save[2] = l_room;
-        }
+        w_save[lane] = make_uint4(w_blk | (w_state != 0u ? 0x80000000u : 0u), w_pos, w_k, w_len | (w_seq << 16));
+        if (lane == 0) u_save[0] = w_next;
         t = try_claim();
         if (t == 0xffffffffu) {
           __builtin_amdgcn_s_sleep(4);
@@ -1810,7 +1842,6 @@ __global__ __launch_bounds__(kThreads) void k_wal_split(WalScanParams p) {
         }
       } else if (wave == 1 && !p_done) {
         if (!(p.tune & 4u)) __builtin_amdgcn_s_setprio(2);
-        p_rd = uni(u_save[4]);
         p_count = uni(u_save[5]);
         p_open = uni(u_save[6]);
         p_spans = uni(u_save[7]);
@@ -1825,7 +1856,6 @@ __global__ __launch_bounds__(kThreads) void k_wal_split(WalScanParams p) {
         }
         if (st == 0) continue;
         if (lane == 0) {
-          u_save[4] = p_rd;
           u_save[5] = p_count;
           u_save[6] = p_open;
           u_save[7] = p_spans;
