@@ -1557,7 +1557,8 @@ __global__ __launch_bounds__(kThreads) void k_wal_split(WalScanParams p) {
     // 64-byte sectors that the record just listed brought within kSplitAhead bytes of the cursor (straight into
     // a few words of LDS that nobody reads: the point is the copy the L2 keeps).  Not while rounds pile up:
     // then the checksum waves are what the scan waits for, and they would find the lines evicted again.
-    if (!(p.tune & 1u) && __any(has && span <= kSplitAheadSpan)) {
+    const uint32_t ahead_span = (p.tune >> 24) & 0x7fu ? ((p.tune >> 24) & 0x7fu) * 64u : kSplitAheadSpan;  // (experiment knob)
+    if (!(p.tune & 1u) && __any(has && span <= ahead_span)) {
       const uint32_t out = p_count >> 3, taken = uni(lds_load(&ctl[0]));
       if (taken + kSplitAheadBacklog > out) {
         const uint64_t bbase = (uint64_t)blk * kLogBlockBytes;
@@ -1569,7 +1570,7 @@ __global__ __launch_bounds__(kThreads) void k_wal_split(WalScanParams p) {
         uint32_t to = ((start + span + ahead) >> 6) + 1u;
         if (to > lim) to = lim;
         if (to > from + 40u) to = from + 40u;
-        if (!has || span > kSplitAheadSpan) to = 0u;
+        if (!has || span > ahead_span) to = 0u;
         typedef const uint32_t __attribute__((address_space(1)))* gp32;
         typedef uint32_t __attribute__((address_space(3)))* lp32;
         const uint8_t* bp = p.img + bbase;

@@ -359,3 +359,33 @@ def test_framing_plan_is_enqueued_twice_over_other_bytes(recycle, phase):
     eng.wal_frame_enqueue(empty, dsrc, dst)
     empty.close()
     eng.close()
+
+
+@pytest.mark.parametrize("blocks_per_workgroup,recycle", [(1, False), (2, True), (3, False), (5, True), (8, False), (17, True)])
+def test_scan_with_few_blocks_per_workgroup(eng, blocks_per_workgroup, recycle):
+    """The walker's lanes share the list's places by the number of blocks a workgroup has (one block: one queue of
+    all places; seventeen: 32 queues): images sized for 1 to 17 blocks per workgroup, records of every size from
+    tiny to several blocks, some of them damaged, block by block against the CPU reader's rules."""
+    import terarkdb_amd.capi as capi
+    props = torch.cuda.get_device_properties(0)
+    nblocks = props.multi_processor_count * blocks_per_workgroup - 3
+    rng = np.random.default_rng(100 + blocks_per_workgroup)
+    filler = O.splitmix(1 << 18, 77).tobytes()
+    t = O.OracleLog(recycle=recycle, log_number=41)
+    while t.written_bytes() < nblocks * 32768:
+        kind = int(rng.integers(0, 10))
+        n = int(rng.integers(0, 60)) if kind < 4 else int(rng.integers(60, 3000)) if kind < 9 else int(rng.integers(3000, 100000))
+        t.write(filler[:n])
+    img = bytearray(t.contents())
+    t.close()
+    recs, n = O.list_physical(bytes(img), 41)
+    for ri in rng.choice(n, size=40, replace=False):
+        off, typ, ln, _ = (int(x) for x in recs[ri])
+        img[off + int(rng.integers(0, (11 if recycle else 7) + ln))] ^= 1 << int(rng.integers(0, 8))
+    img = bytes(img[:len(img) - int(rng.integers(0, 5000))])  # and a torn tail
+    want = O.wal_scan_blocks(img, 41)
+    got, counts, nrec = device_scan(eng, img, 41)
+    assert (got == want).all()
+    assert nrec == int(want[:, 0].sum()) == int(counts[capi.CNT_CHECKED])
+    bad = np.nonzero(want[:, 1] != 0xffffffff)[0]
+    assert int(counts[capi.CNT_FIRST_BAD]) == (int(bad[0]) if bad.size else 2**64 - 1)
