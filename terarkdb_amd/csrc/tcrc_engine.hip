@@ -1414,49 +1414,67 @@ __global__ __launch_bounds__(kThreads) void k_wal_split(WalScanParams p) {
     uint32_t hs = recyc ? kLogRecyclableHeader : kLogHeader;
     const uint32_t lognum = __builtin_amdgcn_alignbyte(hdr.hi, hdr.lo, 3);  // header bytes 7..10
     uint32_t npos = w_pos + hs + len;
-    bool ok = (w_state == 3u) & (npos <= w_len) & ((hdr.lo & 0xffffffu) != 0u) & (!recyc | ((lognum == ln32) & ln_fits));
-    const bool odd = (w_state != 0u) & !ok;
-    if (lanes_where(odd) != 0ull) {
-      if (odd) {
-        const uint64_t base = (uint64_t)w_blk * kLogBlockBytes;
-        const uint64_t end = base + w_len;
-        const bool last = p.tail && end == p.size;
-        uint32_t code = 0;
-        WalHeader h = hdr;
-        if (w_state != 3u) h = wal_fetch(p.img, base + w_pos, end);
-        ok = wal_decode(h, base + w_pos, end, last, p.log_number, &hs, &len, &code);
-        npos = w_pos + hs + len;
-        if (!ok) {  // the block's walk ends here
-          tcrc_wal_block* b = p.blocks + w_blk;
-          b->n_records = w_k;
-          b->end_offset = w_pos;
-          b->end_code = code;
-          atomicAdd(&ctl[6], w_k);  // the workgroup's candidate records
-          w_state = 0u;
-        }
-      }
-    }
-    // from here on a lane has a block exactly if its record is good
-    const unsigned long long m_ok = lanes_where(ok);
-    if (m_ok == 0ull && w_next >= b_hi) {
-      if (lane == 0) lds_store(&ctl[4], 0x80000000u);  // behind the last entry: the LDS performs a wave's operations in order
-      w_done = true;
-      return 2u;
-    }
-    // The next header is asked for before anything else is done with this record - or, by a lane whose queue is
-    // full, the header under its cursor once more: such a lane stays where it is for a step while the others go
-    // on, and its load, like theirs, is waited for where the next step decodes it.
+    // The chain of a block's walk is: header -> where the next one lies -> its load.  So the load goes out here,
+    // before anything is checked - from inside the block whatever the header holds (a position past the place of
+    // the block's last whole header is pulled back to it; what comes back is then not used).  A lane whose queue
+    // is full asks for the header under its cursor once more instead: it stays where it is for a step while the
+    // others go on.  The checks, the queue and the bookkeeping below run while the loads are under way.
     const bool room = ((w_seq - tk) & 0xffffu) < cap;
-    const bool go = ok & room;
-    const uint32_t at = room ? npos : w_pos;
-    const bool fastn = ok & (w_len - at >= 12u);
-    WalHeader nxt = {0u, 0u};
-    if (fastn) {
+    uint32_t at = room ? npos : w_pos;
+    at = at < w_len - 12u ? at : w_len - 12u;  // (lanes in state 3 have twelve bytes and more)
+    WalHeader nxt;
+    {
+      const uint8_t* from = w_state == 3u ? w_ptr() + at + 4u : (const uint8_t*)p.tab_main;  // others read a harmless place
       uint2 w;
-      __builtin_memcpy(&w, w_ptr() + at + 4u, 8);
+      __builtin_memcpy(&w, from, 8);
       nxt.lo = w.x;
       nxt.hi = w.y;
     }
+    bool ok = (w_state == 3u) & (npos <= w_len) & ((hdr.lo & 0xffffffu) != 0u) & (!recyc | ((lognum == ln32) & ln_fits));
+    bool go = ok & room;
+    // One question settles the usual step: has every lane that has a block a good record and room for it?  Only
+    // if not does the wave go through what else can be (a block's end, a bad header, a full queue, no blocks left).
+    const bool active = w_state != 0u;
+    if (lanes_where(active & !go) != 0ull || lanes_where(active) == 0ull) {
+      const bool odd = active & !ok;
+      if (lanes_where(odd) != 0ull) {
+        if (odd) {
+          const uint64_t base = (uint64_t)w_blk * kLogBlockBytes;
+          const uint64_t end = base + w_len;
+          const bool last = p.tail && end == p.size;
+          uint32_t code = 0;
+          WalHeader h = hdr;
+          if (w_state != 3u) h = wal_fetch(p.img, base + w_pos, end);
+          ok = wal_decode(h, base + w_pos, end, last, p.log_number, &hs, &len, &code);
+          npos = w_pos + hs + len;
+          if (!ok) {  // the block's walk ends here
+            tcrc_wal_block* b = p.blocks + w_blk;
+            b->n_records = w_k;
+            b->end_offset = w_pos;
+            b->end_code = code;
+            atomicAdd(&ctl[6], w_k);  // the workgroup's candidate records
+            w_state = 0u;
+          }
+        }
+      }
+      // from here on a lane has a block exactly if its record is good
+      if (lanes_where(ok) == 0ull && w_next >= b_hi) {
+        if (lane == 0) lds_store(&ctl[4], 0x80000000u);  // behind the last entry: the LDS performs a wave's operations in order
+        w_done = true;
+        return 2u;
+      }
+      go = ok & room;
+      if (lanes_where(ok & !room) != 0ull) {
+        // Some queue is full.  If rounds are waiting for checksum waves, the scan is not waiting for the walk: the
+        // walker goes and takes one.  If not - a log of small records, the other waves idle - it walks on with
+        // the lanes that can, unless none can.  (What the lanes have asked for is dropped: the walker fetches the
+        // headers under its cursors when it comes back.)
+        if (lanes_where(go) == 0ull) return 1u;
+        const uint32_t out = uni(lds_load(&ctl[3])), tickets = uni(lds_load(&ctl[0]));
+        if ((int32_t)(out - tickets) >= (int32_t)kSplitHelpMin) return 1u;
+      }
+    }
+    const bool fastn = ok & (w_len - (go ? npos : w_pos) >= 12u);  // what was asked for above is the header the next step needs
     if (go) {
       // the CRC covers the type byte, the log number if any, and the payload: [pos + 6, pos + hs + len)
       rlist[((w_seq & (cap - 1u)) << qs) + (uint32_t)lane] = make_uint2(w_blk, (w_pos + 6u) | ((len + hs - 6u) << 15));
@@ -1468,14 +1486,6 @@ __global__ __launch_bounds__(kThreads) void k_wal_split(WalScanParams p) {
     }
     if (ok) w_state = fastn ? 3u : 1u;
     hdr = nxt;
-    if (lanes_where(ok & !room) != 0ull) {
-      // Some queue is full.  If rounds are waiting for checksum waves, the scan is not waiting for the walk: the
-      // walker goes and takes one (so it did whenever its list was full).  If not - a log of small records, the
-      // other waves idle - it walks on with the lanes that can, unless none can.
-      if (lanes_where(go) == 0ull) return 1u;
-      const uint32_t out = uni(lds_load(&ctl[3])), tickets = uni(lds_load(&ctl[0]));
-      if ((int32_t)(out - tickets) >= (int32_t)kSplitHelpMin) return 1u;
-    }
     if ((++steps & 31u) == 0u && uni(lds_load(&ctl[2])) != 0u) return 0u;
    }
   };
