@@ -1535,7 +1535,9 @@ __global__ __launch_bounds__(kThreads) void k_wal_split(WalScanParams p) {
     if (m_q != 0ull) {
       const uint32_t A = (uint32_t)__popcll(m_q);
       if (avail_q != 0u) qmap[lanes_below(m_q)] = (uint8_t)lane;
-      const uint32_t qd = (uint32_t)((float)lane / (float)A);  // exact: both below 2^24, and a quotient that is no integer is 1/64 off one
+      // lane / A without an integer division: with the half added the quotient is at least 1/128 away from every
+      // integer, far more than the division's rounding
+      const uint32_t qd = (uint32_t)(((float)lane + 0.5f) / (float)A);
       qi = qmap[(uint32_t)lane - qd * A];  // (read behind the writes: one wave's LDS operations are performed in order)
       const uint2 c = qctr[qi];
       has = qd < ((c.x - c.y) & 0xffffu);
