@@ -67,3 +67,19 @@ def test_product_tree_does_not_reference_the_oracle():
                 if "oracle" in text.lower():
                     bad.append(os.path.join(d, f))
     assert not bad, bad
+
+
+def test_shard_range_matches_the_python_arithmetic():
+    """tcrc_shard_range is host arithmetic (no GPU): the C ABI's block-range split is sharding.shard_range, for
+    even and uneven splits, empty corpora and the 64 GiB corpus of the multi-GPU benchmark."""
+    from terarkdb_amd.sharding import shard_range
+    for n in (0, 1, 7, 1003, 8388608, 2**40 + 5):
+        for count in (1, 2, 3, 8, 64):
+            covered = 0
+            for i in range(count):
+                lo, hi = C.c_uint64(0), C.c_uint64(0)
+                capi.lib.tcrc_shard_range(n, i, count, C.byref(lo), C.byref(hi))
+                assert (lo.value, hi.value) == shard_range(n, i, count)
+                assert lo.value == covered
+                covered = hi.value
+            assert covered == n
