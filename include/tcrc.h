@@ -262,6 +262,12 @@ uint32_t tcrc_wal_plan_block_offset(const tcrc_wal_plan* plan);      /* block of
 uint64_t tcrc_wal_plan_physical_records(const tcrc_wal_plan* plan);  /* headers the image holds */
 int tcrc_dev_wal_frame_enqueue(tcrc_ctx* ctx, tcrc_wal_plan* plan, const void* d_src, void* d_dst,
                                uint64_t dst_capacity, void* stream);
+/* By default every enqueue records an event behind its launch, so that tcrc_wal_plan_free can wait for the plan's
+ * last reader whenever it is called; between launches queued back to back that event costs about 3.5 us (113 against
+ * 110 us per launch for 256 MiB of 2040-byte records).  A caller that frames in a loop and waits for its stream
+ * anyway can take that over: after tcrc_wal_plan_caller_waits(plan, 1) no event is recorded, and the plan must not
+ * be freed before the work enqueued with it from then on has finished. */
+int tcrc_wal_plan_caller_waits(tcrc_wal_plan* plan, int yes);
 void tcrc_wal_plan_free(tcrc_wal_plan* plan);
 
 /* Sets d_counts to {0, ~0, 0}. */

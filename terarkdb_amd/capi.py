@@ -78,6 +78,7 @@ SIGNATURES.update({
     "tcrc_wal_framed_size": (_u64, [_vp, _u64, _i, _u32]),
     "tcrc_wal_plan_create": (_i, [_vp, _vp, _u64, _u64, _i, _u32, C.POINTER(_vp)]),
     "tcrc_wal_plan_free": (None, [_vp]),
+    "tcrc_wal_plan_caller_waits": (C.c_int, [_vp, C.c_int]),
     "tcrc_wal_plan_image_bytes": (_u64, [_vp]),
     "tcrc_wal_plan_block_offset": (_u32, [_vp]),
     "tcrc_wal_plan_physical_records": (_u64, [_vp]),
@@ -307,6 +308,10 @@ class WalPlan:
         self.image_bytes = lib.tcrc_wal_plan_image_bytes(handle)
         self.block_offset = lib.tcrc_wal_plan_block_offset(handle)
         self.physical_records = lib.tcrc_wal_plan_physical_records(handle)
+
+    def caller_waits(self, yes=True):
+        """No event behind the launches from now on: the caller waits for its stream before close()."""
+        check(lib.tcrc_wal_plan_caller_waits(self.handle, int(yes)))
 
     def close(self):
         if self.handle:

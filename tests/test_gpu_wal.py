@@ -333,6 +333,8 @@ def test_framing_plan_is_enqueued_twice_over_other_bytes(recycle, phase):
     plan = eng.wal_plan(offs, lens, 77, recycle, block_offset=32768 - hs - 3)
     dst = torch.full((plan.image_bytes + 64,), 0xEE, dtype=torch.uint8, device="cuda")
     for seed in (5, 6):
+        # (the second time with the caller in charge of waiting: no event behind the launch)
+        plan.caller_waits(seed == 6)
         src = O.splitmix((pos + 64 + 7) // 8 * 8, seed)
         records = [src[o:o + ln].tobytes() for o, ln in zip(offs, lens)]
         # the CPU writer continuing a log that stands at the same block offset

@@ -189,12 +189,17 @@ def run_frame(eng):
         w.write(src[int(o):int(o) + ln].tobytes())
     assert dst.cpu().numpy()[:plan.image_bytes].tobytes() == w.contents()
     w.close()
+    sec_tracked = sustained(fn)  # an event behind every launch: the plan may be freed at any time
+    plan.caller_waits(True)     # the loop below waits for its stream before the plan is closed
     sec = sustained(fn)
+    torch.cuda.synchronize()
     line("frame_2040", f"frame {n} records of {ln} bytes resident in HBM into a log image ({plan.physical_records} physical "
                        f"records, {plan.image_bytes} bytes): one kernel reads the payload once, writes the image once and "
                        "checksums what passes through its registers; the plan is made once, outside the launches",
          "k_wal_frame", payload + plan.image_bytes, sec, payload_bytes=payload, image_bytes=int(plan.image_bytes),
-         payload_GBps=round(payload / sec / 1e9, 1), image_equals_cpu_writer=True)
+         payload_GBps=round(payload / sec / 1e9, 1), image_equals_cpu_writer=True,
+         note="launches queued with tcrc_wal_plan_caller_waits(plan, 1): no event behind each launch",
+         avg_launch_us_with_an_event_behind_every_launch=round(sec_tracked * 1e6, 2))
     plan.close()
 
 
