@@ -1498,7 +1498,7 @@ __global__ __launch_bounds__(kThreads) void k_wal_split(WalScanParams p) {
   uint32_t p_spans = 0;  // spans of several pieces so far: span n uses slot n mod kWalSlots
   bool p_done = false;
   // Returns 0 when every span it took found room, 1 when the ring or the slots had no room for some, 2 when the
-  // queues were empty.  Lane l looks at queue l mod Q, at the entry l / Q behind the ones taken so far.
+  // queues were empty.
   // Experiment: rounds the placer may be ahead of the tickets handed out (0: as many as the ring holds)
   const uint32_t lead_max = (p.tune >> 16) & 0xffu;
   auto lead_cap = [&](uint32_t open) -> uint32_t {
